@@ -1,0 +1,490 @@
+/*
+ * ref_driver.c -- TEST INFRASTRUCTURE (oracle side).
+ *
+ * A small program of this repository's own that links against the *compiled reference*
+ * (oracle/_ref/libphyc_ref.so, built by oracle/Makefile from the sources where they lie under
+ * /root/reference) and dumps golden vectors / timings for the tree-likelihood hot path.
+ * It is only ever built where /root/reference exists; nothing from the reference is copied.
+ *
+ * It mirrors the call protocol of the reference's own harness and wrapper:
+ *   - model assembly as examples/benchmarking.c:426-460 (patterns + tree in a hash, likelihood
+ *     node from JSON) and src/phycpp/physher.cpp:34-49 (new_TreeModel_from_newick with the taxa
+ *     in alignment order, so tip id == sequence index);
+ *   - timing protocol as examples/benchmarking.c:466-471 and :498-503.
+ *
+ * Usage:
+ *   ref_driver dump  <spec-file> <out.json>
+ *   ref_driver json  <reference-json-file> <out.json>      (run in the dir holding its data files)
+ *   ref_driver bench <spec-file> <iters> <warmup>
+ *
+ * spec-file: "key value" lines:
+ *   fasta <path>        newick <path-to-file-with-newick>
+ *   datatype nucleotide|aa|codon
+ *   model jc69|hky|gtr|wag|lg|mg94
+ *   rates a,b,c,...     (gtr: ac,ag,at,cg,ct ; hky: kappa ; mg94: kappa,alpha,beta)
+ *   freqs f0,f1,...     (omit for the empirical aa models -> model frequencies)
+ *   categories C        alpha A   (C>1 => discrete gamma)
+ *   tipstates 0|1       sse 0|1   rescale 0|1
+ *   generic_kernels 0|1 (force the generic-state kernels; needed for 61 states, SURVEY 8a note)
+ */
+#include <math.h>
+#include <stdarg.h>
+#include <stdbool.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "phyc/datatype.h"
+#include "phyc/filereader.h"
+#include "phyc/hashtable.h"
+#include "phyc/mjson.h"
+#include "phyc/mg94.h"
+#include "phyc/parameters.h"
+#include "phyc/sequenceio.h"
+#include "phyc/simplex.h"
+#include "phyc/sitemodel.h"
+#include "phyc/sitepattern.h"
+#include "phyc/substmodel.h"
+#include "phyc/tree.h"
+#include "phyc/treelikelihood.h"
+#include "phyc/treelikelihoodX.h"
+
+typedef struct {
+	char fasta[1024], newick[1024], datatype[32], model[32];
+	double rates[16];
+	int nrates;
+	double freqs[80];
+	int nfreqs;
+	int categories;
+	double alpha;
+	int tipstates, sse, rescale, generic_kernels;
+} spec_t;
+
+static int parse_list(const char *s, double *out, int max) {
+	int n = 0;
+	char *tmp = strdup(s), *tok, *save;
+	for (tok = strtok_r(tmp, ",", &save); tok && n < max; tok = strtok_r(NULL, ",", &save)) out[n++] = atof(tok);
+	free(tmp);
+	return n;
+}
+
+static void read_spec(const char *path, spec_t *sp) {
+	memset(sp, 0, sizeof(*sp));
+	strcpy(sp->datatype, "nucleotide");
+	strcpy(sp->model, "jc69");
+	sp->categories = 1;
+	sp->alpha = 0.5;
+	sp->tipstates = 0;
+	sp->sse = 1;
+	FILE *f = fopen(path, "r");
+	if (!f) { fprintf(stderr, "cannot open spec %s\n", path); exit(2); }
+	char key[64], val[4096];
+	while (fscanf(f, "%63s %4095s", key, val) == 2) {
+		if (!strcmp(key, "fasta")) strcpy(sp->fasta, val);
+		else if (!strcmp(key, "newick")) strcpy(sp->newick, val);
+		else if (!strcmp(key, "datatype")) strcpy(sp->datatype, val);
+		else if (!strcmp(key, "model")) strcpy(sp->model, val);
+		else if (!strcmp(key, "rates")) sp->nrates = parse_list(val, sp->rates, 16);
+		else if (!strcmp(key, "freqs")) sp->nfreqs = parse_list(val, sp->freqs, 80);
+		else if (!strcmp(key, "categories")) sp->categories = atoi(val);
+		else if (!strcmp(key, "alpha")) sp->alpha = atof(val);
+		else if (!strcmp(key, "tipstates")) sp->tipstates = atoi(val);
+		else if (!strcmp(key, "sse")) sp->sse = atoi(val);
+		else if (!strcmp(key, "rescale")) sp->rescale = atoi(val);
+		else if (!strcmp(key, "generic_kernels")) sp->generic_kernels = atoi(val);
+		else { fprintf(stderr, "unknown spec key %s\n", key); exit(2); }
+	}
+	fclose(f);
+}
+
+static char *slurp(const char *path) {
+	FILE *f = fopen(path, "r");
+	if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+	fseek(f, 0, SEEK_END);
+	long n = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	char *b = malloc(n + 1);
+	if (fread(b, 1, n, f) != (size_t)n) { fprintf(stderr, "short read\n"); exit(2); }
+	b[n] = 0;
+	while (n > 0 && (b[n - 1] == '\n' || b[n - 1] == '\r' || b[n - 1] == ' ')) b[--n] = 0;
+	fclose(f);
+	return b;
+}
+
+typedef struct {
+	Model *mlike;
+	Model *mtree;
+	SitePattern *patterns;
+	Hashtable *hash;
+	json_node *json;
+} built_t;
+
+static void append(char **buf, size_t *len, size_t *cap, const char *fmt, ...) {
+	va_list ap;
+	for (;;) {
+		va_start(ap, fmt);
+		int n = vsnprintf(*buf + *len, *cap - *len, fmt, ap);
+		va_end(ap);
+		if ((size_t)n < *cap - *len) { *len += n; return; }
+		*cap = (*cap + n) * 2;
+		*buf = realloc(*buf, *cap);
+	}
+}
+
+static built_t build_from_spec(const spec_t *sp) {
+	built_t b;
+	memset(&b, 0, sizeof(b));
+	b.hash = new_Hashtable_string(100);
+	hashtable_set_key_ownership(b.hash, false);
+	hashtable_set_value_ownership(b.hash, false);
+
+	Sequences *sequences = readSequences(sp->fasta);
+	bool codon = !strcmp(sp->datatype, "codon");
+	if (codon) sequences->datatype = new_CodonDataType(0);
+	else if (!strcmp(sp->datatype, "aa")) sequences->datatype = new_AminoAcidDataType();
+	else sequences->datatype = new_NucleotideDataType();
+	b.patterns = new_SitePattern(sequences);
+	int ntaxa = sequences->size;
+	char **taxa = malloc(sizeof(char *) * ntaxa);
+	for (int i = 0; i < ntaxa; i++) taxa[i] = strdup(b.patterns->names[i]);
+	free_Sequences(sequences);
+	Hashtable_add(b.hash, "patterns", b.patterns);
+
+	char *newick = slurp(sp->newick);
+	b.mtree = new_TreeModel_from_newick(newick, taxa, NULL);
+	free(newick);
+	Hashtable_add(b.hash, "tree", b.mtree);
+
+	size_t cap = 8192, len = 0;
+	char *js = malloc(cap);
+	js[0] = 0;
+	append(&js, &len, &cap, "{\"id\":\"treelikelihood\",\"type\":\"treelikelihood\",\"sse\":%s,\"tipstates\":%s,\"sitepattern\":\"&patterns\",\"tree\":\"&tree\",",
+	       sp->sse ? "true" : "false", sp->tipstates ? "true" : "false");
+	/* site model */
+	append(&js, &len, &cap, "\"sitemodel\":{\"id\":\"sitemodel\",\"type\":\"sitemodel\"");
+	if (sp->categories > 1) {
+		append(&js, &len, &cap,
+		       ",\"distribution\":{\"distribution\":\"gamma\",\"categories\":%d,\"parameters\":{\"alpha\":{\"id\":\"alpha\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}}}",
+		       sp->categories, sp->alpha);
+	}
+	append(&js, &len, &cap, "}");
+	if (!codon) {
+		append(&js, &len, &cap, ",\"substitutionmodel\":{\"id\":\"sm\",\"type\":\"substitutionmodel\",\"model\":\"%s\",\"datatype\":\"%s\"", sp->model, sp->datatype);
+		if (sp->nfreqs > 0) {
+			append(&js, &len, &cap, ",\"frequencies\":{\"id\":\"freqs\",\"type\":\"Simplex\",\"values\":[");
+			for (int i = 0; i < sp->nfreqs; i++) append(&js, &len, &cap, "%s%.17g", i ? "," : "", sp->freqs[i]);
+			append(&js, &len, &cap, "]}");
+		}
+		if (!strcmp(sp->model, "gtr")) {
+			const char *nm[5] = {"ac", "ag", "at", "cg", "ct"};
+			append(&js, &len, &cap, ",\"rates\":{");
+			for (int i = 0; i < 5; i++)
+				append(&js, &len, &cap, "%s\"%s\":{\"id\":\"%s\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}", i ? "," : "", nm[i], nm[i], sp->rates[i]);
+			append(&js, &len, &cap, "}");
+		} else if (!strcmp(sp->model, "hky")) {
+			append(&js, &len, &cap, ",\"rates\":{\"kappa\":{\"id\":\"kappa\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}}", sp->rates[0]);
+		}
+		append(&js, &len, &cap, "}");
+	}
+	append(&js, &len, &cap, "}");
+
+	if (!codon) {
+		b.json = create_json_tree(js);
+		b.mlike = new_TreeLikelihoodModel_from_json(b.json, b.hash);
+	} else {
+		/* SubstitutionModel_factory has empty bodies for MG94 (substmodel.c:1526-1544): use the C constructors. */
+		int S = b.patterns->nstate;
+		Simplex *fs = new_Simplex("freqs", S);
+		if (sp->nfreqs == S) fs->set_values(fs, sp->freqs);
+		Model *mfs = new_SimplexModel("freqs", fs);
+		SubstitutionModel *m = new_MG94_with_values(fs, sp->rates[1], sp->rates[2], sp->rates[0], 0);
+		Model *mm = new_SubstitutionModel2("sm", m, mfs, NULL);
+		mfs->free(mfs);
+		/* site model through JSON (no substitution model inside) */
+		char sjs[1024];
+		if (sp->categories > 1)
+			snprintf(sjs, sizeof sjs,
+			         "{\"id\":\"sitemodel\",\"type\":\"sitemodel\",\"distribution\":{\"distribution\":\"gamma\",\"categories\":%d,\"parameters\":{\"alpha\":{\"id\":\"alpha\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}}}}",
+			         sp->categories, sp->alpha);
+		else
+			snprintf(sjs, sizeof sjs, "{\"id\":\"sitemodel\",\"type\":\"sitemodel\"}");
+		b.json = create_json_tree(sjs);
+		Model *msm = new_SiteModel_from_json(b.json, b.hash);
+		SingleTreeLikelihood *tlk = new_SingleTreeLikelihood((Tree *)b.mtree->obj, m, (SiteModel *)msm->obj, b.patterns, NULL, sp->tipstates);
+		b.patterns->ref_count++;
+		b.mlike = new_TreeLikelihoodModel("treelikelihood", tlk, b.mtree, mm, msm, NULL);
+		mm->free(mm);
+		msm->free(msm);
+	}
+	free(js);
+	SingleTreeLikelihood *tlk = b.mlike->obj;
+	if (sp->generic_kernels || codon) {
+		/* generic-state kernels (treelikelihoodX.c); the codon dispatcher is stale (SURVEY 8a notes) */
+		SingleTreeLikelihood_enable_SSE(tlk, false);
+		tlk->update_partials = update_partials_general;
+		tlk->integrate_partials = integrate_partials_general;
+		tlk->node_log_likelihoods = node_log_likelihoods_general;
+		tlk->calculate_per_cat_partials = calculate_branch_partials;
+	}
+	if (sp->rescale) SingleTreeLikelihood_use_rescaling(tlk, true);
+	for (int i = 0; i < ntaxa; i++) free(taxa[i]);
+	free(taxa);
+	return b;
+}
+
+static void jnum(FILE *o, double v);
+
+static void jarr(FILE *o, const char *key, const double *v, size_t n, bool comma) {
+	fprintf(o, "\"%s\":[", key);
+	for (size_t i = 0; i < n; i++) {
+		if (i) fprintf(o, ",");
+		jnum(o, v[i]);
+	}
+	fprintf(o, "]%s\n", comma ? "," : "");
+}
+
+static void jnum(FILE *o, double v) {
+	if (isnan(v)) fprintf(o, "NaN");
+	else if (isinf(v)) fprintf(o, v > 0 ? "Infinity" : "-Infinity");
+	else fprintf(o, "%.17g", v);
+}
+
+static void dump_common(FILE *o, Model *mlike) {
+	SingleTreeLikelihood *tlk = mlike->obj;
+	Tree *tree = tlk->tree;
+	SitePattern *sp = tlk->sp;
+	int N = Tree_node_count(tree), T = Tree_tip_count(tree), P = sp->count, S = tlk->m->nstate, C = tlk->cat_count;
+
+	fprintf(o, "\"tip_count\":%d,\"node_count\":%d,\"pattern_count\":%d,\"state_count\":%d,\"category_count\":%d,\n", T, N, P, S, C);
+	fprintf(o, "\"taxa\":[");
+	for (int i = 0; i < sp->size; i++) fprintf(o, "%s\"%s\"", i ? "," : "", sp->names[i]);
+	fprintf(o, "],\n");
+	jarr(o, "weights", sp->weights, P, true);
+	fprintf(o, "\"patterns\":[");
+	for (int i = 0; i < sp->size; i++) {
+		fprintf(o, "%s[", i ? "," : "");
+		for (int k = 0; k < P; k++) fprintf(o, "%s%d", k ? "," : "", (int)sp->patterns[i][k]);
+		fprintf(o, "]");
+	}
+	fprintf(o, "],\n");
+
+	/* first evaluation: lnL (also fills matrices, partials, pattern_lk) */
+	double lnl = mlike->logP(mlike);
+	fprintf(o, "\"lnl\":");
+	jnum(o, lnl);
+	fprintf(o, ",\n\"rescaled\":%s,\n", tlk->scale ? "true" : "false");
+	jarr(o, "pattern_lk", tlk->pattern_lk, P, true);
+
+	fprintf(o, "\"nodes\":[");
+	for (int i = 0; i < N; i++) {
+		Node *n = Tree_node(tree, i);
+		fprintf(o, "%s{\"id\":%d,\"class_id\":%d,\"name\":\"%s\",\"left\":%d,\"right\":%d,\"parent\":%d,\"distance\":%.17g,\"mapping\":%d}", i ? "," : "", n->id,
+		        n->class_id, n->name ? n->name : "", n->left ? n->left->id : -1, n->right ? n->right->id : -1, n->parent ? n->parent->id : -1,
+		        Node_distance(n), tlk->mapping[n->id]);
+	}
+	fprintf(o, "],\n\"root\":%d,\n", Tree_root(tree)->id);
+
+	tlk->sm->update(tlk->sm);
+	double *rates = malloc(sizeof(double) * C);
+	for (int c = 0; c < C; c++) rates[c] = tlk->sm->get_rate(tlk->sm, c);
+	jarr(o, "cat_rates", rates, C, true);
+	free(rates);
+	jarr(o, "cat_proportions", tlk->sm->get_proportions(tlk->sm), C, true);
+	jarr(o, "frequencies", tlk->get_root_frequencies(tlk), S, true);
+	jarr(o, "eval", tlk->m->eigendcmp->eval, S, true);
+	{
+		double *tmp = malloc(sizeof(double) * S * S);
+		for (int i = 0; i < S; i++)
+			for (int j = 0; j < S; j++) tmp[i * S + j] = tlk->m->eigendcmp->evec[i][j];
+		jarr(o, "evec", tmp, (size_t)S * S, true);
+		for (int i = 0; i < S; i++)
+			for (int j = 0; j < S; j++) tmp[i * S + j] = tlk->m->eigendcmp->Invevec[i][j];
+		jarr(o, "ivec", tmp, (size_t)S * S, true);
+		if (tlk->m->Q) {
+			for (int i = 0; i < S; i++)
+				for (int j = 0; j < S; j++) tmp[i * S + j] = tlk->m->Q[i][j];
+			jarr(o, "Q", tmp, (size_t)S * S, true);
+		}
+		free(tmp);
+	}
+	/* P(t) of three non-root nodes: node 0 (a tip), first internal, last non-root.  Fresh p_t calls (never transposed). */
+	{
+		int pick[3] = {0, T, N - 2};
+		double *mat = malloc(sizeof(double) * S * S * 2);
+		fprintf(o, "\"pt_nodes\":[%d,%d,%d],\n", pick[0], pick[1], pick[2]);
+		fprintf(o, "\"pt\":[");
+		for (int q = 0; q < 3; q++) {
+			Node *n = Tree_node(tree, pick[q]);
+			fprintf(o, "%s[", q ? "," : "");
+			for (int c = 0; c < C; c++) {
+				tlk->m->p_t(tlk->m, Node_distance(n) * tlk->sm->get_rate(tlk->sm, c), mat);
+				for (int i = 0; i < S * S; i++) fprintf(o, "%s%.17g", (c || i) ? "," : "", mat[i]);
+			}
+			fprintf(o, "]");
+		}
+		fprintf(o, "],\n\"dpt\":[");
+		for (int q = 0; q < 3; q++) {
+			Node *n = Tree_node(tree, pick[q]);
+			fprintf(o, "%s[", q ? "," : "");
+			for (int c = 0; c < C; c++) {
+				tlk->m->dp_dt(tlk->m, Node_distance(n) * tlk->sm->get_rate(tlk->sm, c), mat);
+				for (int i = 0; i < S * S; i++) fprintf(o, "%s%.17g", (c || i) ? "," : "", mat[i]);
+			}
+			fprintf(o, "]");
+		}
+		fprintf(o, "],\n");
+		free(mat);
+	}
+	/* lower partials of the root and of the first internal node, reference layout [C][P][S] */
+	{
+		int ids[2] = {T, Tree_root(tree)->id};
+		const char *nm[2] = {"partials_first_internal", "partials_root"};
+		for (int q = 0; q < 2; q++) jarr(o, nm[q], tlk->partials[tlk->current_partials_indexes[ids[q]]][ids[q]], (size_t)C * P * S, true);
+		if (tlk->scale) jarr(o, "scaling_root", tlk->scaling_factors[tlk->current_partials_indexes[ids[1]]][ids[1]], P, true);
+	}
+}
+
+static void dump_gradients_unrooted(FILE *o, Model *mlike) {
+	SingleTreeLikelihood *tlk = mlike->obj;
+	int N = Tree_node_count(tlk->tree);
+	/* branch-length gradient only (the headline metric): flag TREE_MODEL */
+	size_t len = TreeLikelihood_initialize_gradient(mlike, TREELIKELIHOOD_FLAG_TREE_MODEL);
+	SingleTreeLikelihood_update_all_nodes(tlk);
+	double *g = TreeLikelihood_gradient(mlike);
+	jarr(o, "gradient_tree", g, len, true);
+	/* upper partials of the first internal node and of tip 0 (valid after the gradient call) */
+	{
+		int T = Tree_tip_count(tlk->tree);
+		size_t sz = (size_t)tlk->cat_count * tlk->sp->count * tlk->m->nstate;
+		int ids[2] = {0, T};
+		const char *nm[2] = {"upper_tip0", "upper_first_internal"};
+		for (int q = 0; q < 2; q++) {
+			int idx = tlk->upper_partial_indexes[ids[q]];
+			jarr(o, nm[q], tlk->partials[tlk->current_partials_indexes[idx]][idx], sz, true);
+		}
+	}
+	/* tree + site model + substitution model ("next"-tier rows G2).  flags==0 is NOT used: with it
+	 * TreeLikelihood_initialize_gradient under-counts the substitution block (treelikelihood.c:248-249
+	 * are evaluated before :259) and TreeLikelihood_calculate_gradient overruns tlk->gradient. */
+	{
+		int flags = TREELIKELIHOOD_FLAG_TREE_MODEL;
+		if (tlk->sm->proportions != NULL || Parameters_count(tlk->sm->rates) > 0 || tlk->sm->mu != NULL) flags |= TREELIKELIHOOD_FLAG_SITE_MODEL;
+		if (tlk->m->dPdp != NULL) flags |= TREELIKELIHOOD_FLAG_SUBSTITUTION_MODEL;
+		len = TreeLikelihood_initialize_gradient(mlike, flags);
+		SingleTreeLikelihood_update_all_nodes(tlk);
+		g = TreeLikelihood_gradient(mlike);
+		jarr(o, "gradient_all", g, len, true);
+		fprintf(o, "\"gradient_all_flags\":%d,\"gradient_all_tree_len\":%d,\n", flags, N);
+	}
+}
+
+static double now_ms(void) {
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC_RAW, &t);
+	return t.tv_sec * 1000. + t.tv_nsec / 1e6;
+}
+
+int main(int argc, char **argv) {
+	if (argc < 4) {
+		fprintf(stderr, "usage: %s dump|json|bench ...\n", argv[0]);
+		return 2;
+	}
+	if (!strcmp(argv[1], "dump")) {
+		spec_t sp;
+		read_spec(argv[2], &sp);
+		built_t b = build_from_spec(&sp);
+		FILE *o = fopen(argv[3], "w");
+		fprintf(o, "{\n");
+		dump_common(o, b.mlike);
+		dump_gradients_unrooted(o, b.mlike);
+		fprintf(o, "\"source\":\"physher reference (libphyc no-GSL build) via oracle/ref_driver.c\"\n}\n");
+		fclose(o);
+		return 0;
+	}
+	if (!strcmp(argv[1], "json")) {
+		/* a reference-format JSON document whose first child is a treelikelihood node (tests/data/jc69-time.json) */
+		Hashtable *hash = new_Hashtable_string(10);
+		hashtable_set_key_ownership(hash, false);
+		hashtable_set_value_ownership(hash, false);
+		char *content = load_file(argv[2]);
+		json_node *json = create_json_tree(content);
+		free(content);
+		Model *model = new_TreeLikelihoodModel_from_json(json->children[0], hash);
+		SingleTreeLikelihood *tlk = model->obj;
+		Tree_update_heights(tlk->tree);
+		FILE *o = fopen(argv[3], "w");
+		fprintf(o, "{\n");
+		for (int jac = 0; jac < 2; jac++) {
+			tlk->include_jacobian = jac;
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			double lnl = model->logP(model);
+			fprintf(o, "\"lnl_jacobian%d\":%.17g,\n", jac, lnl);
+			size_t len = TreeLikelihood_initialize_gradient(model, TREELIKELIHOOD_FLAG_TREE_MODEL | TREELIKELIHOOD_FLAG_BRANCH_MODEL);
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			double *g = TreeLikelihood_gradient(model);
+			char key[64];
+			snprintf(key, sizeof key, "gradient_tree_clock_jacobian%d", jac);
+			jarr(o, key, g, len, true);
+		}
+		tlk->include_jacobian = false;
+		SingleTreeLikelihood_update_all_nodes(tlk);
+		{
+			Tree *tree = tlk->tree;
+			int N = Tree_node_count(tree);
+			double *h = malloc(sizeof(double) * N), *bl = malloc(sizeof(double) * N);
+			for (int i = 0; i < N; i++) {
+				Node *n = Tree_node(tree, i);
+				h[i] = Node_height(n);
+				bl[i] = Node_isroot(n) ? 0 : tlk->bm->get(tlk->bm, n) * Node_time_elapsed(n);
+			}
+			jarr(o, "heights", h, N, true);
+			jarr(o, "branch_lengths", bl, N, true);
+			free(h);
+			free(bl);
+		}
+		dump_common(o, model);
+		fprintf(o, "\"source\":\"physher reference via oracle/ref_driver.c json mode\"\n}\n");
+		fclose(o);
+		return 0;
+	}
+	if (!strcmp(argv[1], "bench")) {
+		spec_t sp;
+		read_spec(argv[2], &sp);
+		int iters = atoi(argv[3]);
+		int warm = argc > 4 ? atoi(argv[4]) : 1;
+		built_t b = build_from_spec(&sp);
+		SingleTreeLikelihood *tlk = b.mlike->obj;
+		double lnl = 0;
+		for (int i = 0; i < warm; i++) {
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			tlk->m->need_update = true;
+			lnl = b.mlike->logP(b.mlike);
+		}
+		double t0 = now_ms();
+		for (int i = 0; i < iters; i++) {
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			tlk->m->need_update = true;
+			lnl = b.mlike->logP(b.mlike);
+		}
+		double t1 = now_ms();
+		TreeLikelihood_initialize_gradient(b.mlike, TREELIKELIHOOD_FLAG_TREE_MODEL);
+		for (int i = 0; i < warm; i++) {
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			tlk->m->need_update = true;
+			TreeLikelihood_gradient(b.mlike);
+		}
+		double t2 = now_ms();
+		for (int i = 0; i < iters; i++) {
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			tlk->m->need_update = true;
+			TreeLikelihood_gradient(b.mlike);
+		}
+		double t3 = now_ms();
+		printf("{\"lnl\":%.17g,\"iters\":%d,\"lnl_ms_per_eval\":%.6f,\"grad_ms_per_eval\":%.6f,\"patterns\":%d,\"taxa\":%d,\"rescaled\":%s}\n", lnl, iters,
+		       (t1 - t0) / iters, (t3 - t2) / iters, tlk->sp->count, Tree_tip_count(tlk->tree), tlk->scale ? "true" : "false");
+		return 0;
+	}
+	fprintf(stderr, "unknown mode %s\n", argv[1]);
+	return 2;
+}

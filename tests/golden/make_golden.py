@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the COMPILED REFERENCE.
+
+Runs only where /root/reference exists (this container): builds oracle/_ref (the reference's own
+sources compiled where they lie, see oracle/Makefile) and drives it through oracle/ref_driver.c.
+Inputs are seeded synthetic alignments/trees from physher_amd/synth.py, plus the reference's own
+test data files (tests/data/fluA.fa + jc69-time.json: data fixtures of its known-answer test).
+
+Each case directory holds: aln.fa, tree.nwk, spec.txt (inputs) and expected.json.gz (outputs of the
+reference).  Re-running this script must reproduce the committed files byte for byte.
+"""
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from physher_amd import synth  # noqa: E402
+
+REF = os.environ.get("PHYSHER_REF", "/root/reference")
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+GTR_RATES = "1.2,3.1,0.7,0.9,2.8"
+GTR_FREQS = "0.3,0.2,0.2,0.3"
+
+AA_FREQS = ",".join(repr(x) for x in (np.arange(1, 21) / 210.0).tolist())
+
+CASES = [
+    # name, dict(options)
+    ("gtr_g4_t16", dict(T=16, sites=400, seed=1, datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.5)),
+    ("gtr_g4_t16_tipstates", dict(T=16, sites=400, seed=1, datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.5, tipstates=1)),
+    ("gtr_g4_t16_scalar", dict(T=16, sites=400, seed=1, datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.5, sse=0)),
+    ("gtr_g4_t24_gaps", dict(T=24, sites=500, seed=2, datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.7, gaps=0.05)),
+    ("gtr_g4_t24_gaps_tipstates", dict(T=24, sites=500, seed=2, datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.7, gaps=0.05, tipstates=1)),
+    ("jc69_t12", dict(T=12, sites=300, seed=3, datatype="nucleotide", model="jc69", freqs="0.25,0.25,0.25,0.25", categories=1)),
+    ("hky_g3_t10", dict(T=10, sites=300, seed=4, datatype="nucleotide", model="hky", rates="2.5", freqs="0.1,0.2,0.3,0.4", categories=3, alpha=1.3)),
+    ("gtr_g4_caterpillar_t20", dict(T=20, sites=300, seed=5, shape="caterpillar", datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.5)),
+    ("gtr_g1_t96_rescale", dict(T=96, sites=150, seed=6, bl=(0.3, 0.9), datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=1, rescale=1)),
+    ("gtr_g4_t96_rescale", dict(T=96, sites=150, seed=6, bl=(0.3, 0.9), datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.5, rescale=1)),
+    ("gtr_g4_t700_autorescale", dict(T=700, sites=20, seed=7, bl=(0.5, 1.5), datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.5, slim=1)),
+    ("wag_g4_t12", dict(T=12, sites=80, seed=8, datatype="aa", model="wag", categories=4, alpha=0.5)),
+    ("wag_g4_t12_tipstates", dict(T=12, sites=80, seed=8, datatype="aa", model="wag", categories=4, alpha=0.5, tipstates=1)),
+    # LG without explicit frequencies crashes in the reference (lg.c:47 builds a 0-dimensional simplex): pass them
+    ("lg_g1_t9_gaps", dict(T=9, sites=60, seed=9, datatype="aa", model="lg", categories=1, gaps=0.05, freqs=AA_FREQS)),
+    ("mg94_t8", dict(T=8, sites=40, seed=10, datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=1)),
+    ("mg94_g2_t6_tipstates", dict(T=6, sites=30, seed=11, datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=2, alpha=0.8, tipstates=1)),
+]
+
+STATE_COUNT = {"nucleotide": 4, "aa": 20, "codon": 61}
+# bulky arrays dropped from "slim" cases
+SLIM_DROP = ("partials_first_internal", "partials_root", "upper_tip0", "upper_first_internal", "pt", "dpt")
+
+
+def build_ref():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref", f"REF={REF}"])
+
+
+def run_case(name, o):
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(o["seed"])
+    lo, hi = o.get("bl", (0.01, 0.1))
+    tree = synth.random_tree(o["T"], rng, shape=o.get("shape", "random"), bl_low=lo, bl_high=hi)
+    S = STATE_COUNT[o["datatype"]]
+    states = synth.evolve(tree, o["sites"], S, rng)
+    fasta = synth.to_fasta(tree.names, states, o["datatype"], o.get("gaps", 0.0), rng)
+    with open(os.path.join(d, "aln.fa"), "w") as f:
+        f.write(fasta)
+    with open(os.path.join(d, "tree.nwk"), "w") as f:
+        f.write(tree.newick() + "\n")
+    spec = [f"fasta {d}/aln.fa", f"newick {d}/tree.nwk", f"datatype {o['datatype']}", f"model {o['model']}"]
+    for k in ("rates", "freqs", "categories", "alpha", "tipstates", "sse", "rescale"):
+        if k in o:
+            spec.append(f"{k} {o[k]}")
+    tmp_spec = os.path.join(d, "spec.abs.txt")
+    with open(tmp_spec, "w") as f:
+        f.write("\n".join(spec) + "\n")
+    # the committed spec uses paths relative to the case directory
+    with open(os.path.join(d, "spec.txt"), "w") as f:
+        f.write("\n".join(s.replace(d + "/", "") for s in spec) + "\n")
+    out = os.path.join(d, "expected.json")
+    subprocess.check_call([DRIVER, "dump", tmp_spec, out], stdout=subprocess.DEVNULL)
+    os.remove(tmp_spec)
+    with open(out) as f:
+        data = json.load(f)
+    if o.get("slim"):
+        for k in SLIM_DROP:
+            data.pop(k, None)
+    os.remove(out)
+    with gzip.GzipFile(out + ".gz", "w", mtime=0) as f:
+        f.write(json.dumps(data, separators=(",", ":")).encode())
+    print(f"{name}: T={data['tip_count']} P={data['pattern_count']} S={data['state_count']} C={data['category_count']} "
+          f"lnL={data['lnl']!r} rescaled={data['rescaled']}")
+
+
+def run_fluA():
+    """The reference's only known-answer case (tests/test_tree_likelihood.c) through the driver's json mode."""
+    d = os.path.join(HERE, "fluA_jc69_time")
+    os.makedirs(d, exist_ok=True)
+    for fn in ("fluA.fa", "jc69-time.json"):
+        shutil.copyfile(os.path.join(REF, "tests", "data", fn), os.path.join(d, fn))
+    out = os.path.join(d, "expected.json")
+    subprocess.check_call([DRIVER, "json", "jc69-time.json", out], cwd=d, stdout=subprocess.DEVNULL)
+    with open(out) as f:
+        data = json.load(f)
+    os.remove(out)
+    for k in SLIM_DROP:
+        data.pop(k, None)
+    with gzip.GzipFile(out + ".gz", "w", mtime=0) as f:
+        f.write(json.dumps(data, separators=(",", ":")).encode())
+    print(f"fluA_jc69_time: lnL={data['lnl_jacobian0']!r} (reference test constant -4777.616349713985), "
+          f"lnL+jac={data['lnl_jacobian1']!r} (-4786.867701371271)")
+
+
+if __name__ == "__main__":
+    build_ref()
+    only = sys.argv[1:]
+    for name, opts in CASES:
+        if not only or name in only:
+            run_case(name, opts)
+    if not only or "fluA_jc69_time" in only:
+        run_fluA()
