@@ -1,0 +1,160 @@
+"""ctypes binding of oracle/libphyoracle.so -- TEST INFRASTRUCTURE, never imported by physher_amd."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NUCLEOTIDE, AMINO_ACID, CODON = 0, 1, 2
+DATATYPES = {"nucleotide": NUCLEOTIDE, "aa": AMINO_ACID, "codon": CODON}
+
+
+class _Problem(C.Structure):
+    _fields_ = [
+        ("tip_count", C.c_int), ("node_count", C.c_int), ("pattern_count", C.c_int),
+        ("state_count", C.c_int), ("cat_count", C.c_int),
+        ("left", C.c_void_p), ("right", C.c_void_p), ("root", C.c_int),
+        ("tip_states", C.c_void_p), ("tip_partials", C.c_void_p), ("weights", C.c_void_p),
+        ("eval", C.c_void_p), ("evec", C.c_void_p), ("ivec", C.c_void_p), ("freqs", C.c_void_p),
+        ("cat_rates", C.c_void_p), ("cat_props", C.c_void_p), ("branch_lengths", C.c_void_p),
+        ("rescale", C.c_int), ("compat_scaled_gradient", C.c_int), ("fold_root_freqs", C.c_int),
+    ]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libphyoracle.so")
+    src = [os.path.join(_HERE, f) for f in ("phyoracle.c", "phyoracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libphyoracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.phyo_log_likelihood.restype = C.c_double
+        _LIB.phyo_gradient.restype = C.c_double
+        _LIB.phyo_encode_symbol.argtypes = [C.c_int, C.c_char_p]
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def encode_alignment(datatype: str, sequences) -> np.ndarray:
+    """sequences: list of str.  Returns site-major columns uint8 [site_count][taxon_count]."""
+    dt = DATATYPES[datatype]
+    step = 3 if dt == CODON else 1
+    L = lib()
+    nsites = len(sequences[0]) // step
+    cols = np.empty((nsites, len(sequences)), dtype=np.uint8)
+    for t, s in enumerate(sequences):
+        b = s.encode()
+        for k in range(nsites):
+            cols[k, t] = L.phyo_encode_symbol(dt, b[k * step:k * step + step])
+    return cols
+
+
+def compress_patterns(columns: np.ndarray):
+    columns = np.ascontiguousarray(columns, dtype=np.uint8)
+    nsites, T = columns.shape
+    pat = np.empty(T * max(nsites, 1), dtype=np.uint8)
+    w = np.empty(max(nsites, 1), dtype=np.float64)
+    n = C.c_int(0)
+    lib().phyo_compress_patterns(_p(columns), nsites, T, _p(pat), _p(w), C.byref(n))
+    P = n.value
+    return pat[:T * P].reshape(T, P).copy(), w[:P].copy()
+
+
+def state_partials(datatype: str, state_count: int, codes: np.ndarray) -> np.ndarray:
+    """codes uint8 [...] -> float64 [..., S] tip partial vectors (ambiguity masks for nucleotides)."""
+    dt = DATATYPES[datatype]
+    out = np.empty(codes.shape + (state_count,), dtype=np.float64)
+    flat = out.reshape(-1, state_count)
+    L = lib()
+    tmp = (C.c_double * state_count)()
+    cache = {}
+    for i, c in enumerate(codes.reshape(-1)):
+        c = int(c)
+        if c not in cache:
+            L.phyo_state_partial(dt, state_count, c, tmp)
+            cache[c] = np.array(tmp[:])
+        flat[i] = cache[c]
+    return out
+
+
+def p_t(S, eval_, evec, ivec, t, derivative=False):
+    out = np.empty((S, S))
+    fn = lib().phyo_dp_dt if derivative else lib().phyo_p_t
+    fn(S, _p(np.ascontiguousarray(eval_)), _p(np.ascontiguousarray(evec)), _p(np.ascontiguousarray(ivec)), C.c_double(t), _p(out))
+    return out
+
+
+class Problem:
+    """Flat description of one likelihood evaluation (mirrors phyo_problem)."""
+
+    def __init__(self, left, right, root, weights, eval_, evec, ivec, freqs, cat_rates, cat_props, branch_lengths,
+                 tip_states=None, tip_partials=None, rescale=0, compat_scaled_gradient=0, fold_root_freqs=0):
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.left = np.ascontiguousarray(left, dtype=np.int32)
+        self.right = np.ascontiguousarray(right, dtype=np.int32)
+        self.root = int(root)
+        self.weights = f64(weights)
+        self.eval, self.evec, self.ivec, self.freqs = f64(eval_), f64(evec), f64(ivec), f64(freqs)
+        self.cat_rates, self.cat_props = f64(cat_rates), f64(cat_props)
+        self.branch_lengths = f64(branch_lengths)
+        self.tip_states = None if tip_states is None else np.ascontiguousarray(tip_states, dtype=np.uint8)
+        self.tip_partials = None if tip_partials is None else f64(tip_partials)
+        self.N = len(self.left)
+        self.T = (self.N + 1) // 2
+        self.P = len(self.weights)
+        self.S = len(self.freqs)
+        self.C = len(self.cat_rates)
+        self.rescale = rescale
+        self.compat_scaled_gradient = compat_scaled_gradient
+        self.fold_root_freqs = fold_root_freqs
+
+    def _c(self):
+        return _Problem(self.T, self.N, self.P, self.S, self.C, _p(self.left), _p(self.right), self.root,
+                        _p(self.tip_states), _p(self.tip_partials), _p(self.weights), _p(self.eval), _p(self.evec),
+                        _p(self.ivec), _p(self.freqs), _p(self.cat_rates), _p(self.cat_props), _p(self.branch_lengths),
+                        self.rescale, self.compat_scaled_gradient, self.fold_root_freqs)
+
+    def log_likelihood(self, want_lower=False):
+        plk = np.empty(self.P)
+        lower = np.empty((self.N, self.C, self.P, self.S)) if want_lower else None
+        scaling = np.empty((self.N, self.P)) if want_lower else None
+        on = C.c_int(0)
+        pb = self._c()
+        lnl = lib().phyo_log_likelihood(C.byref(pb), _p(plk), _p(lower), _p(scaling), C.byref(on))
+        return dict(lnl=lnl, pattern_lk=plk, lower=lower, scaling=scaling, rescaled=bool(on.value))
+
+    def gradient(self, want_partials=False):
+        plk = np.empty(self.P)
+        g = np.zeros((self.N, self.C))
+        lower = np.empty((self.N, self.C, self.P, self.S)) if want_partials else None
+        upper = np.empty((self.N, self.C, self.P, self.S)) if want_partials else None
+        on = C.c_int(0)
+        pb = self._c()
+        lnl = lib().phyo_gradient(C.byref(pb), _p(plk), _p(g), _p(lower), _p(upper), C.byref(on))
+        return dict(lnl=lnl, pattern_lk=plk, cat_grad=g, lower=lower, upper=upper, rescaled=bool(on.value))
+
+
+def branch_gradient_from_cat(cat_grad, cat_rates, cat_props, zero_node=None):
+    """G1 epilogue for unrooted trees (treelikelihood.c:3129-3143, 3249-3255)."""
+    g = np.array(cat_grad, dtype=np.float64, copy=True)
+    if zero_node is not None:
+        g[zero_node, :] = 0.0
+    if g.shape[1] == 1:
+        return g[:, 0].copy()
+    out = g[:, 0] * cat_props[0] * cat_rates[0]
+    for j in range(1, g.shape[1]):
+        out = out + g[:, j] * cat_props[j] * cat_rates[j]
+    return out
