@@ -1,0 +1,145 @@
+/*
+ * physher_amd.h -- C ABI of the MI355X (gfx950) tree-likelihood engine.
+ *
+ * This is the drop-in boundary for physher's Felsenstein-pruning hot path.  Every entry point is
+ * plain C (pointers + sizes, no C++/torch types) and replaces one piece of what
+ * `struct _SingleTreeLikelihood` and its five kernel function pointers do on the CPU in the
+ * reference (src/phyc/treelikelihood.h:46-124).  The reference-side binding a maintainer would add
+ * is shown in INTEGRATION.md.
+ *
+ * Conventions shared with the reference:
+ *   - node ids: tips 0..T-1, internal nodes T..2T-2, children before parents not required
+ *     (src/phyc/tree.c:183-224); the root may be any internal node.
+ *   - host-side array layouts are the reference's: partials [C][P][S] (state fastest,
+ *     treelikelihood.c:1028), matrices [C][S][S] row-major P[parent state][child state]
+ *     (substmodel.c:547-555), tip states uint8, code >= S = unknown/gap (sitepattern.h:68-82).
+ *   - numerical trouble is reported in-band like the reference does: NaN/inf lnL and an all-NaN
+ *     gradient (treelikelihood.c:327-332, 1489-1519).  API misuse and device errors return a
+ *     negative PHYAMD_E* code; phyamd_last_error() holds the message.  Nothing here calls exit().
+ *
+ * All functions are single-caller per engine (the reference's objects are not thread-safe either,
+ * SURVEY.md section 8b); different engines may be used from different threads.
+ */
+#ifndef PHYSHER_AMD_H
+#define PHYSHER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct phyamd_engine phyamd_engine;
+
+enum {
+	PHYAMD_OK = 0,
+	PHYAMD_EINVAL = -1,   /* bad argument / call order */
+	PHYAMD_EDEVICE = -2,  /* HIP runtime error (message in phyamd_last_error) */
+	PHYAMD_ENOMEM = -3,   /* device memory exhausted */
+	PHYAMD_EUNSUPPORTED = -4
+};
+
+/* rescaling policy: SingleTreeLikelihood_use_rescaling + the lazy switch of treelikelihood.c:1496-1519 */
+enum { PHYAMD_RESCALE_NEVER = 0, PHYAMD_RESCALE_ALWAYS = 1, PHYAMD_RESCALE_AUTO = 2 };
+
+/* gradient flags */
+enum {
+	/* Multiply the root frequencies into the upper partials of the root's children and drop them from
+	 * the final state sum: the reference's `include_root_freqs = true` mode (treelikelihood.c:241,
+	 * 2147-2153), which it uses when no substitution-model gradient is requested.  That mode is only
+	 * exact for uniform frequencies; the default (0) is the reference's `include_root_freqs = false`
+	 * arithmetic (treelikelihood.c:2715-2751), exact for every reversible model. */
+	PHYAMD_GRAD_FOLD_ROOT_FREQS = 1,
+	/* Under rescaling divide each category's derivative by that category's own site likelihood, as
+	 * treelikelihood.c:2851-2870 does, instead of by the mixture likelihood. */
+	PHYAMD_GRAD_COMPAT_SCALED = 2
+};
+
+typedef struct {
+	int32_t tip_count;      /* T */
+	int32_t pattern_count;  /* P (this engine's shard of the compressed patterns) */
+	int32_t state_count;    /* S: 4, 20, 61, ... */
+	int32_t category_count; /* C */
+	int32_t device;         /* HIP device ordinal; -1 = current device */
+	int32_t rescale;        /* PHYAMD_RESCALE_* */
+	int64_t max_device_bytes; /* 0 = no cap; otherwise patterns are processed in tiles that fit */
+	void *stream;           /* hipStream_t to run on, NULL = engine-owned stream */
+} phyamd_config;
+
+/* --- life cycle: new_SingleTreeLikelihood / free_SingleTreeLikelihood (treelikelihood.c:1007-1185) --- */
+int phyamd_create(const phyamd_config *cfg, phyamd_engine **out);
+void phyamd_destroy(phyamd_engine *e);
+const char *phyamd_last_error(void);
+/* version of this ABI (bumped on any signature change) */
+int phyamd_abi_version(void);
+
+/* --- data: sp->patterns / sp->weights / tlk->partials of tips (sitepattern.h:68-82, treelikelihood.c:1106-1117) --- */
+/* states[P] codes of one tip ("tipstates": true semantics; code >= S => all ones). */
+int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states);
+/* partials[P][S] of one tip ("tipstates": false semantics: ambiguity masks or any likelihood vector);
+ * replicated over categories like treelikelihood.c:1111-1114. */
+int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials);
+int phyamd_set_pattern_weights(phyamd_engine *e, const double *weights /* [P] */);
+
+/* --- tree: Tree/Node ids, Node_left/right (tree.c:183-224) --- */
+int phyamd_set_topology(phyamd_engine *e, const int32_t *left, const int32_t *right /* [2T-1], -1 for tips */, int root);
+/* branch length per node id, already multiplied by the clock rate for time trees
+ * (treelikelihood.c:1652-1663); the root entry is ignored. */
+int phyamd_set_branch_lengths(phyamd_engine *e, const double *lengths /* [2T-1] */);
+
+/* --- models: SubstitutionModel eigen system + frequencies, SiteModel rates/proportions --- */
+/* eval[S], evec[S][S], ivec[S][S]: m->eigendcmp after update_eigen_system (substmodel.c:1092-1115);
+ * P(t) = |evec diag(exp(eval t)) ivec| is formed on the device (substmodel.c:518-557). */
+int phyamd_set_eigen(phyamd_engine *e, const double *eval, const double *evec, const double *ivec);
+int phyamd_set_frequencies(phyamd_engine *e, const double *freqs /* [S] */);
+/* sm->get_rate(c) (includes mu) and sm->get_proportions (sitemodel.c:544-549) */
+int phyamd_set_category_rates(phyamd_engine *e, const double *rates /* [C] */, const double *proportions /* [C] */);
+/* Optional: explicit matrices [C][S][S] for one node (closed-form models: jc69.c:73-79, hky.c:230-273).
+ * Cleared by phyamd_set_eigen. */
+int phyamd_set_node_matrices(phyamd_engine *e, int node, const double *matrices);
+/* Rate matrix Q [S][S] (rows sum to 0, normalised like substmodel.c:1135-1143).  The gradient kernels use
+ * (dP/dt) p = Q (P p) instead of a second matrix per branch (the reference's dp_dt, substmodel.c:695-723, is the
+ * same product).  phyamd_set_eigen derives Q itself; only explicit-matrix users need this call. */
+int phyamd_set_rate_matrix(phyamd_engine *e, const double *Q);
+
+/* --- evaluation --- */
+/* lnL = sum_k w_k log L_k: _calculate_simple (treelikelihood.c:1454-1526). */
+int phyamd_log_likelihood(phyamd_engine *e, double *lnl);
+/* lnL and the per-category branch gradient g[node][c] = sum_k w_k (dL_kc/dt_node) / L_k:
+ * update_upper_partials + gradient_cat_branch_lengths (treelikelihood.c:2129-2161, 2793-2941).
+ * cat_gradient [2T-1][C]; the root row is 0.  NaN/inf lnL => all-NaN gradient. */
+int phyamd_gradient(phyamd_engine *e, int flags, double *lnl, double *cat_gradient);
+/* Same, then the epilogue gradient_branch_length_from_cat_inplace (treelikelihood.c:3129-3143):
+ * branch_gradient[node] = sum_c g[node][c] w_c r_c  (r_c WITHOUT mu: pass them here).  [2T-1]. */
+int phyamd_branch_gradient(phyamd_engine *e, int flags, const double *rates_without_mu /* [C] or NULL */, double *lnl,
+                           double *branch_gradient);
+/* Device-resident result for multi-GPU sharding: writes [lnL, g[0][0..C-1], g[1][..], ...]
+ * (1 + (2T-1)*C doubles) to `device_out` on the engine's stream, no host synchronisation. */
+int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out);
+int phyamd_synchronize(phyamd_engine *e);
+
+/* --- inspection (parity tests, debugging) --- */
+int phyamd_get_pattern_log_likelihoods(phyamd_engine *e, double *out /* [P] */);
+/* lower (upper=0) or upper (upper=1) partials of a node after the last evaluation, reference layout
+ * [C][P][S]. Upper partials exist only after phyamd_gradient with keep_partials enabled. */
+int phyamd_get_partials(phyamd_engine *e, int node, int upper, double *out);
+int phyamd_get_node_matrices(phyamd_engine *e, int node, int derivative, double *out /* [C][S][S] */);
+int phyamd_is_rescaling(phyamd_engine *e);
+/* keep every node's upper partials resident after a gradient call (costs memory; off by default) */
+int phyamd_set_keep_partials(phyamd_engine *e, int on);
+
+/* --- measurement --- */
+typedef struct {
+	double matrices_ms, lower_ms, upper_ms, reduce_ms; /* HIP-event time per kernel family, last evaluation */
+	int32_t lower_launches, upper_launches;
+	int64_t device_bytes; /* resident device memory of this engine */
+	int32_t tiles;         /* pattern tiles per evaluation */
+} phyamd_profile;
+int phyamd_set_profiling(phyamd_engine *e, int on);
+int phyamd_get_profile(phyamd_engine *e, phyamd_profile *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1116 @@
+// phyamd_engine.hip -- MI355X (gfx950) tree-likelihood engine behind include/physher_amd.h.
+//
+// Replaces the CPU hot path of physher's SingleTreeLikelihood (src/phyc/treelikelihood.c and the
+// per-state-count kernel files) with hand-written HIP kernels.  Design:
+//   * one thread owns one site pattern and loops over the rate categories, so per-pattern work
+//     (rescaling max, mixture denominators, weights) never leaves the thread;
+//   * transition matrices P(t) and dP/dt are built on the device from the cached eigen system and
+//     reach the kernels through wave-uniform (scalar) loads;
+//   * the tree is executed level by level: one launch covers every node of a level
+//     (blockIdx.y = node, blockIdx.x = pattern block), so launch count = tree height, not node count;
+//   * the pre-order pass computes BOTH children's upper partials from one read of the parent's upper
+//     and fuses the branch-length gradient (dP/dt contraction, state sum, 1/L_k, weights, pattern
+//     reduction) into the same kernel: the reference's spare_partials array never exists;
+//   * reductions are fixed-order (wave shuffle -> LDS -> per-block slab -> reduction kernel), so
+//     results are bitwise reproducible run to run.
+//
+// gfx950 only; no CUDA/compat paths.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "physher_amd.h"
+
+#define PHYAMD_ABI_VERSION 1
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+	do {                                                                                                    \
+		hipError_t err__ = (expr);                                                                          \
+		if (err__ != hipSuccess)                                                                            \
+			return fail(err__ == hipErrorOutOfMemory ? PHYAMD_ENOMEM : PHYAMD_EDEVICE, "%s: %s (%s:%d)", #expr, \
+			            hipGetErrorString(err__), __FILE__, __LINE__);                                      \
+	} while (0)
+
+constexpr int WAVE = 64;             // lanes per wavefront (gfx950)
+constexpr int PPT = 4;               // pattern groups swept by one workgroup (sequentially, one barrier each)
+constexpr int MAX_WAVES = 16;        // 1024 threads
+constexpr double SCALING_THRESHOLD = 1.0e-40;  // treelikelihood.c:1121
+
+struct NodeOp {
+	int32_t parent;  // lower pass: destination node; upper pass: the node whose children are produced
+	int32_t left, right;
+	int32_t upper_slot_parent;  // upper pass: slot of the parent's upper (-1: parent is the root)
+	int32_t upper_slot_left, upper_slot_right;  // slots to write (-1: child is a tip, nothing stored)
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+
+struct d4 {
+	double x, y, z, w;
+};
+
+__device__ __forceinline__ d4 load4(const double *p) {
+	// 32 contiguous bytes per lane: two 16-byte loads (global_load_dwordx4)
+	const double2 a = reinterpret_cast<const double2 *>(p)[0];
+	const double2 b = reinterpret_cast<const double2 *>(p)[1];
+	return d4{a.x, a.y, b.x, b.y};
+}
+
+__device__ __forceinline__ void store4(double *p, const d4 &v) {
+	reinterpret_cast<double2 *>(p)[0] = double2{v.x, v.y};
+	reinterpret_cast<double2 *>(p)[1] = double2{v.z, v.w};
+}
+
+// tip vector from a 4-bit ambiguity mask (one-hot for a known state, 0xF for a gap: datatype.h:26-66)
+__device__ __forceinline__ d4 mask4(unsigned m) {
+	return d4{(m & 1u) ? 1.0 : 0.0, (m & 2u) ? 1.0 : 0.0, (m & 4u) ? 1.0 : 0.0, (m & 8u) ? 1.0 : 0.0};
+}
+
+// y = M v, M row-major 4x4 at a wave-uniform address (scalar loads)
+__device__ __forceinline__ d4 matvec4(const double *__restrict__ M, const d4 &v) {
+	d4 r;
+	r.x = M[0] * v.x + M[1] * v.y + M[2] * v.z + M[3] * v.w;
+	r.y = M[4] * v.x + M[5] * v.y + M[6] * v.z + M[7] * v.w;
+	r.z = M[8] * v.x + M[9] * v.y + M[10] * v.z + M[11] * v.w;
+	r.w = M[12] * v.x + M[13] * v.y + M[14] * v.z + M[15] * v.w;
+	return r;
+}
+
+__device__ __forceinline__ d4 mul4(const d4 &a, const d4 &b) { return d4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+__device__ __forceinline__ double max4(const d4 &a) { return fmax(fmax(a.x, a.y), fmax(a.z, a.w)); }
+__device__ __forceinline__ double dot4(const d4 &a, const d4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// fixed-order sum over the 64 lanes of a wave; every lane ends with the total
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+// Make a wave-uniform pointer opaque to the optimiser.  The matrices are loop-invariant inside the
+// pattern-group loop; without this LLVM hoists all of them out of the loop, runs out of SGPRs and
+// parks them in VGPR lanes (v_writelane/v_readlane pairs around every use).  Re-issuing the scalar
+// loads per group costs a few s_load_dwordx16 from the scalar cache instead.
+__device__ __forceinline__ const double *opaque(const double *p) {
+	asm volatile("" : "+s"(p));
+	return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M1/M2: P(t) and dP/dt for every (node, category) from the eigen system (substmodel.c:518-557, 695-723)
+// ------------------------------------------------------------------------------------------------
+// model layout: eval[S] | evec[S*S] | ivec[S*S]
+__global__ void k_transition_matrices(int S, int C, int node_count, const double *__restrict__ model, const double *__restrict__ rates,
+                                      const double *__restrict__ lengths, const uint8_t *__restrict__ is_explicit, int root,
+                                      double *__restrict__ mats, double *__restrict__ dmats) {
+	const size_t total = (size_t)node_count * C * S * S;
+	const double *eval = model, *evec = model + S, *ivec = model + S + S * S;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		const int j = idx % S;
+		const int i = (idx / S) % S;
+		const int c = (idx / ((size_t)S * S)) % C;
+		const int n = idx / ((size_t)S * S * C);
+		if (n == root || is_explicit[n]) continue;
+		const double t = lengths[n] * rates[c];
+		double p = 0., dp = 0.;
+		for (int k = 0; k < S; k++) {
+			const double e = exp(eval[k] * t);
+			const double w = ivec[k * S + j] * evec[i * S + k];
+			p += w * e;
+			dp += w * (eval[k] * e);
+		}
+		mats[idx] = fabs(p);  // substmodel.c:552
+		dmats[idx] = dp;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// 4-state kernels.  Workgroup = (64 lanes = patterns) x (C waves = categories) x (G pattern groups);
+// a wave's category is uniform, so its 4x4 matrices live in SGPRs and feed v_fma_f64 directly.
+// Cross-category quantities (rescaling max, mixture sums) go through a small LDS exchange.
+// ------------------------------------------------------------------------------------------------
+// lower: internal-node partials, node n at lower + (n - T) * C*P*4, layout [C][P][4] (the reference's)
+// tipmask: [T][P] 4-bit ambiguity masks
+// lscale: [(N - T)][P] cumulative log scale factors (SCALE only)
+// dynamic LDS: 4 * G*C*64 doubles (two double-buffered exchanges) + G doubles (reduction)
+template <bool SCALE, bool ROOT>
+__global__ __launch_bounds__(MAX_WAVES *WAVE) void k_lower4(const NodeOp *__restrict__ ops, int T, int P, int C,
+                                                            const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
+                                                            const double *__restrict__ mats, double *__restrict__ lscale,
+                                                            const double *__restrict__ freqs, const double *__restrict__ props,
+                                                            const double *__restrict__ weights, double *__restrict__ pattern_lk,
+                                                            double *__restrict__ lnl_part) {
+	extern __shared__ double sh[];
+	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
+	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
+	const NodeOp op = ops[blockIdx.y];
+	const size_t plane = (size_t)P * 4;  // one category of one node
+	const bool ltip = op.left < T, rtip = op.right < T;
+	const double *Ml = mats + ((size_t)op.left * C + c) * 16;
+	const double *Mr = mats + ((size_t)op.right * C + c) * 16;
+	const double *pl = ltip ? nullptr : lower + ((size_t)(op.left - T) * C + c) * plane;
+	const double *pr = rtip ? nullptr : lower + ((size_t)(op.right - T) * C + c) * plane;
+	double *dst = lower + ((size_t)(op.parent - T) * C + c) * plane;
+	const int xsz = G * C * WAVE;  // one exchange buffer
+	double acc = 0.0;
+
+#pragma unroll 1
+	for (int q = 0; q < PPT; q++) {
+		const int k0 = ((blockIdx.x * PPT + q) * G + g) * WAVE + lane;
+		const bool valid = k0 < P;
+		const int k = valid ? k0 : P - 1;
+		const d4 a = ltip ? mask4(tipmask[(size_t)op.left * P + k]) : load4(pl + (size_t)k * 4);
+		const d4 b = rtip ? mask4(tipmask[(size_t)op.right * P + k]) : load4(pr + (size_t)k * 4);
+		d4 out = mul4(matvec4(opaque(Ml), a), matvec4(opaque(Mr), b));
+		double sf = 0.0;
+		if (SCALE) {  // SingleTreeLikelihood_scalePartials (treelikelihood.c:1790-1836): max over categories and states
+			double *xb = sh + (q & 1) * xsz;
+			xb[(g * C + c) * WAVE + lane] = max4(out);
+			__syncthreads();
+			double m = 0.0;
+			for (int cc = 0; cc < C; cc++) m = fmax(m, xb[(g * C + cc) * WAVE + lane]);
+			if (m < SCALING_THRESHOLD) {
+				out = d4{out.x / m, out.y / m, out.z / m, out.w / m};
+				sf = log(m);
+			}
+			if (!ltip) sf += lscale[(size_t)(op.left - T) * P + k];
+			if (!rtip) sf += lscale[(size_t)(op.right - T) * P + k];
+			if (c == 0 && valid) lscale[(size_t)(op.parent - T) * P + k] = sf;
+		}
+		if (valid) store4(dst + (size_t)k * 4, out);
+		if (ROOT) {  // integrate_partials + node_log_likelihoods + weighted sum (treelikelihood.c:1473-1487)
+			double *yb = sh + (2 + (q & 1)) * xsz;
+			yb[(g * C + c) * WAVE + lane] = props[c] * (freqs[0] * out.x + freqs[1] * out.y + freqs[2] * out.z + freqs[3] * out.w);
+			__syncthreads();
+			if (c == 0) {
+				double L = 0.0;
+				for (int cc = 0; cc < C; cc++) L += yb[(g * C + cc) * WAVE + lane];
+				const double lk = log(L) + sf;
+				if (valid) {
+					pattern_lk[k] = lk;
+					acc += lk * weights[k];
+				}
+			}
+		}
+	}
+	if (ROOT) {
+		double *red = sh + 4 * xsz;
+		const double s = wave_sum(acc);
+		if (lane == 0 && c == 0) red[g] = s;
+		__syncthreads();
+		if (lane == 0 && c == 0 && g == 0) {
+			double t = red[0];
+			for (int gg = 1; gg < G; gg++) t += red[gg];
+			lnl_part[blockIdx.x] = t;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 + K8 fused, 4 states: one level of the pre-order pass
+// ------------------------------------------------------------------------------------------------
+// For a parent p with children l, r, per (pattern k, category c):
+//   a   = P_p u_p                      (parent is the root: a = pi if FOLD else 1)
+//   bl  = P_l p_l,  br = P_r p_r
+//   u_l = a o br,   u_r = a o bl                                       (treelikelihood.c:2142-2147)
+//   den_c  = sum_i f_i a_i bl_i br_i      = L_kc in this branch's (scaled) units
+//   num_lc = sum_i f_i u_l,i (Q bl)_i     since (dP/dt) p = Q P p     (treelikelihood.c:2846-2939), f = 1 if FOLD else pi
+//   g[l][c] += w_k num_lc / sum_c' w_c' den_c'       (COMPAT: / den_c, treelikelihood.c:2851-2870)
+// upper: slot s at upper + s * C*P*4.  gpart: [(N*C)][nblk] per-block partial sums.
+// dynamic LDS: 6 * G*C*64 doubles (three double-buffered exchanges) + 2*G*C doubles (reduction)
+template <bool SCALE, bool FOLD, bool COMPAT>
+__global__ __launch_bounds__(MAX_WAVES *WAVE) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
+                                                            const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
+                                                            double *__restrict__ upper, const double *__restrict__ mats,
+                                                            const double *__restrict__ Q, const double *__restrict__ freqs,
+                                                            const double *__restrict__ props, const double *__restrict__ weights,
+                                                            double *__restrict__ gpart, int nblk) {
+	extern __shared__ double sh[];
+	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
+	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
+	const NodeOp op = ops[blockIdx.y];
+	const size_t plane = (size_t)P * 4;
+	const bool ltip = op.left < T, rtip = op.right < T, proot = op.upper_slot_parent < 0;
+	const double *Mp = mats + ((size_t)op.parent * C + c) * 16;
+	const double *Ml = mats + ((size_t)op.left * C + c) * 16;
+	const double *Mr = mats + ((size_t)op.right * C + c) * 16;
+	const double *pl = ltip ? nullptr : lower + ((size_t)(op.left - T) * C + c) * plane;
+	const double *pr = rtip ? nullptr : lower + ((size_t)(op.right - T) * C + c) * plane;
+	const double *up = proot ? nullptr : upper + ((size_t)op.upper_slot_parent * C + c) * plane;
+	double *ul_dst = op.upper_slot_left < 0 ? nullptr : upper + ((size_t)op.upper_slot_left * C + c) * plane;
+	double *ur_dst = op.upper_slot_right < 0 ? nullptr : upper + ((size_t)op.upper_slot_right * C + c) * plane;
+	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
+	const d4 one = d4{1., 1., 1., 1.};
+	const d4 f = FOLD ? one : pi;
+	const int xsz = G * C * WAVE;
+	double gl = 0.0, gr = 0.0;
+
+#pragma unroll 1
+	for (int q = 0; q < PPT; q++) {
+		const int k0 = ((blockIdx.x * PPT + q) * G + g) * WAVE + lane;
+		const bool valid = k0 < P;
+		const int k = valid ? k0 : P - 1;
+		const d4 vl = ltip ? mask4(tipmask[(size_t)op.left * P + k]) : load4(pl + (size_t)k * 4);
+		const d4 vr = rtip ? mask4(tipmask[(size_t)op.right * P + k]) : load4(pr + (size_t)k * 4);
+		const d4 a = proot ? (FOLD ? pi : one) : matvec4(opaque(Mp), load4(up + (size_t)k * 4));
+		const d4 bl = matvec4(opaque(Ml), vl);
+		const d4 br = matvec4(opaque(Mr), vr);
+		d4 ul = mul4(a, br), ur = mul4(a, bl);
+		const double den = dot4(mul4(f, a), mul4(bl, br));
+		const double numl = dot4(mul4(f, ul), matvec4(opaque(Q), bl));
+		const double numr = dot4(mul4(f, ur), matvec4(opaque(Q), br));
+		double *xb = sh + (q & 1) * 3 * xsz;
+		const int xi = (g * C + c) * WAVE + lane;
+		xb[xi] = props[c] * den;
+		if (SCALE) {
+			xb[xsz + xi] = max4(ul);
+			xb[2 * xsz + xi] = max4(ur);
+		}
+		__syncthreads();
+		double D = 0.0;
+		for (int cc = 0; cc < C; cc++) D += xb[(g * C + cc) * WAVE + lane];
+		const double w = valid ? weights[k] : 0.0;
+		const double d = (SCALE && COMPAT) ? den : D;
+		gl += w * numl / d;
+		gr += w * numr / d;
+		if (SCALE) {  // uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796); the factors cancel in num/den
+			double ml = 0.0, mr = 0.0;
+			for (int cc = 0; cc < C; cc++) {
+				ml = fmax(ml, xb[xsz + (g * C + cc) * WAVE + lane]);
+				mr = fmax(mr, xb[2 * xsz + (g * C + cc) * WAVE + lane]);
+			}
+			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
+			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
+		}
+		if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
+		if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
+	}
+	// fixed-order reduction: lanes (shuffle) -> pattern groups (LDS) -> one slab entry per (child, category)
+	double *red = sh + 6 * xsz;
+	const double sl = wave_sum(gl), sr = wave_sum(gr);
+	if (lane == 0) {
+		red[(g * C + c) * 2] = sl;
+		red[(g * C + c) * 2 + 1] = sr;
+	}
+	__syncthreads();
+	if (lane == 0 && g == 0) {
+		double tl = red[c * 2], tr = red[c * 2 + 1];
+		for (int gg = 1; gg < G; gg++) {
+			tl += red[(gg * C + c) * 2];
+			tr += red[(gg * C + c) * 2 + 1];
+		}
+		gpart[((size_t)op.left * C + c) * nblk + blockIdx.x] = tl;
+		gpart[((size_t)op.right * C + c) * nblk + blockIdx.x] = tr;
+	}
+}
+
+// fixed-order reduction of per-block slabs: one wave per row. out[row_offset + row] = sum_b part[row][b]
+__global__ __launch_bounds__(64) void k_reduce_rows(const double *__restrict__ part, int nblk, const uint8_t *__restrict__ row_valid,
+                                                   double *__restrict__ out) {
+	const int row = blockIdx.x;
+	double s = 0.0;
+	if (row_valid == nullptr || row_valid[row]) {
+		for (int b = threadIdx.x; b < nblk; b += 64) s += part[(size_t)row * nblk + b];
+		s = wave_sum(s);
+	}
+	if (threadIdx.x == 0) out[row] = s;
+}
+
+__global__ void k_fill_nan(double *out, int n) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// layout conversion helpers for phyamd_set_tip_partials with S == 4 when values are 0/1 masks are done on the host.
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+
+struct phyamd_engine {
+	phyamd_config cfg{};
+	int T = 0, N = 0, P = 0, S = 0, C = 0, root = -1;
+	int G = 1;  // pattern groups (waves along z) per workgroup
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+
+	std::vector<int32_t> left, right, parent;
+	std::vector<double> lengths, model, freqs, rates, props;
+	std::vector<uint8_t> explicit_host;
+	bool have_topology = false, have_lengths = false, have_eigen = false, have_freqs = false, have_rates = false, have_weights = false;
+	std::vector<uint8_t> tip_set;
+	bool matrices_dirty = true;
+	bool scaling_on = false;
+	bool keep_partials = false;
+	bool profiling = false;
+	bool upper_valid = false;
+
+	// schedule
+	std::vector<NodeOp> lower_ops, upper_ops;
+	std::vector<int> lower_level_off, upper_level_off;  // offsets into the op arrays, one past the last at the end
+	std::vector<int32_t> upper_slot;                    // node -> slot of its upper partial in the last schedule (-1 none)
+	int upper_slots = 0;
+
+	// device memory
+	uint8_t *d_tipmask = nullptr;
+	double *d_lower = nullptr, *d_upper = nullptr, *d_mats = nullptr, *d_dmats = nullptr;
+	double *d_Q = nullptr;
+	bool have_Q = false;
+	double *d_model = nullptr, *d_freqs = nullptr, *d_rates = nullptr, *d_props = nullptr, *d_lengths = nullptr, *d_weights = nullptr;
+	double *d_plk = nullptr, *d_lscale = nullptr, *d_lnl_part = nullptr, *d_gpart = nullptr, *d_result = nullptr;
+	uint8_t *d_explicit = nullptr, *d_row_valid = nullptr;
+	NodeOp *d_lower_ops = nullptr, *d_upper_ops = nullptr;
+	double *h_result = nullptr;  // pinned
+	int nblk = 0;
+	int64_t device_bytes = 0;
+	size_t upper_alloc_slots = 0;
+
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	phyamd_profile prof{};
+};
+
+namespace {
+
+template <typename Tp>
+int dev_alloc(phyamd_engine *e, Tp **p, size_t count) {
+	if (count == 0) count = 1;
+	HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(Tp)));
+	e->device_bytes += (int64_t)(count * sizeof(Tp));
+	return PHYAMD_OK;
+}
+
+template <typename Tp>
+void dev_free(phyamd_engine *e, Tp **p, size_t count) {
+	if (*p) {
+		(void)hipFree(*p);
+		e->device_bytes -= (int64_t)((count ? count : 1) * sizeof(Tp));
+		*p = nullptr;
+	}
+}
+
+int bind_device(phyamd_engine *e) {
+	HIP_TRY(hipSetDevice(e->device));
+	return PHYAMD_OK;
+}
+
+size_t node_partial_doubles(const phyamd_engine *e) { return (size_t)e->C * e->P * e->S; }
+
+// Build the level schedule and the upper-slot assignment.
+int build_schedule(phyamd_engine *e) {
+	const int N = e->N, T = e->T;
+	e->parent.assign(N, -1);
+	std::vector<int> seen(N, 0);
+	for (int n = 0; n < N; n++) {
+		const int l = e->left[n], r = e->right[n];
+		if (n < T) {
+			if (l != -1 || r != -1) return fail(PHYAMD_EINVAL, "node %d is a tip (id < tip_count) but has children", n);
+			continue;
+		}
+		if (l < 0 || r < 0 || l >= N || r >= N || l == r) return fail(PHYAMD_EINVAL, "internal node %d has invalid children (%d, %d)", n, l, r);
+		if (++seen[l] > 1 || ++seen[r] > 1) return fail(PHYAMD_EINVAL, "node %d or %d has two parents", l, r);
+		e->parent[l] = n;
+		e->parent[r] = n;
+	}
+	if (e->root < T || e->root >= N || e->parent[e->root] != -1) return fail(PHYAMD_EINVAL, "root %d is not a parentless internal node", e->root);
+	// depth (root = 0) by a stack walk; also detects unreachable nodes / cycles
+	std::vector<int> depth(N, -1), order;
+	order.reserve(N);
+	std::vector<int> stack{e->root};
+	depth[e->root] = 0;
+	while (!stack.empty()) {
+		const int n = stack.back();
+		stack.pop_back();
+		order.push_back(n);
+		if (n >= T) {
+			for (int ch : {e->left[n], e->right[n]}) {
+				depth[ch] = depth[n] + 1;
+				stack.push_back(ch);
+			}
+		}
+	}
+	if ((int)order.size() != N) return fail(PHYAMD_EINVAL, "topology is not a single binary tree over all %d nodes", N);
+	// height (tips = 0), children before parents: reverse of the pre-order list
+	std::vector<int> height(N, 0);
+	int H = 0, Dmax = 0;
+	for (int i = N - 1; i >= 0; i--) {
+		const int n = order[i];
+		if (n >= T) height[n] = 1 + std::max(height[e->left[n]], height[e->right[n]]);
+		H = std::max(H, height[n]);
+		Dmax = std::max(Dmax, depth[n]);
+	}
+	// lower levels: internal nodes by height 1..H (the root has the largest height and is alone on its level)
+	e->lower_ops.clear();
+	e->lower_level_off.assign(1, 0);
+	for (int h = 1; h <= H; h++) {
+		for (int n = T; n < N; n++)
+			if (height[n] == h) e->lower_ops.push_back(NodeOp{n, e->left[n], e->right[n], -1, -1, -1});
+		e->lower_level_off.push_back((int)e->lower_ops.size());
+	}
+	// upper levels: parents by depth 0..Dmax-1.  Upper partials of depth-d nodes are only read while
+	// depth d+1 is produced, so slots are recycled two levels later (keep_partials: slot = own index).
+	e->upper_ops.clear();
+	e->upper_level_off.assign(1, 0);
+	e->upper_slot.assign(N, -1);
+	std::vector<int> free_slots;
+	int next_slot = 0;
+	std::vector<std::vector<int>> slots_of_depth(Dmax + 2);
+	for (int d = 0; d < Dmax; d++) {
+		if (!e->keep_partials && d >= 2) {  // uppers of depth d-1 were consumed while producing depth d
+			for (int s : slots_of_depth[d - 1]) free_slots.push_back(s);
+			slots_of_depth[d - 1].clear();
+		}
+		for (int n = T; n < N; n++) {
+			if (depth[n] != d) continue;
+			NodeOp op{n, e->left[n], e->right[n], n == e->root ? -1 : e->upper_slot[n], -1, -1};
+			for (int side = 0; side < 2; side++) {
+				const int ch = side ? e->right[n] : e->left[n];
+				if (ch < T && !e->keep_partials) continue;  // tips' uppers are never read again
+				int s;
+				if (e->keep_partials) s = ch;
+				else if (!free_slots.empty()) {
+					s = free_slots.back();
+					free_slots.pop_back();
+				} else
+					s = next_slot++;
+				e->upper_slot[ch] = s;
+				slots_of_depth[d + 1].push_back(s);
+				(side ? op.upper_slot_right : op.upper_slot_left) = s;
+			}
+			e->upper_ops.push_back(op);
+		}
+		e->upper_level_off.push_back((int)e->upper_ops.size());
+	}
+	e->upper_slots = e->keep_partials ? N : next_slot;
+	return PHYAMD_OK;
+}
+
+int upload_schedule(phyamd_engine *e) {
+	// op tables are a few KB: allocated once at the maximum size (N - T ops each)
+	int rc;
+	if (!e->d_lower_ops && (rc = dev_alloc(e, &e->d_lower_ops, (size_t)e->N))) return rc;
+	if (!e->d_upper_ops && (rc = dev_alloc(e, &e->d_upper_ops, (size_t)e->N))) return rc;
+	HIP_TRY(hipMemcpyAsync(e->d_lower_ops, e->lower_ops.data(), e->lower_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipMemcpyAsync(e->d_upper_ops, e->upper_ops.data(), e->upper_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
+	// rows of the gradient slab that are produced by the upper pass (every non-root node)
+	std::vector<uint8_t> valid((size_t)e->N * e->C, 1);
+	for (int c = 0; c < e->C; c++) valid[(size_t)e->root * e->C + c] = 0;
+	HIP_TRY(hipMemcpyAsync(e->d_row_valid, valid.data(), valid.size(), hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return PHYAMD_OK;
+}
+
+int ensure_upper_storage(phyamd_engine *e) {
+	const size_t need = (size_t)std::max(1, e->upper_slots);
+	if (e->d_upper && e->upper_alloc_slots >= need) return PHYAMD_OK;
+	dev_free(e, &e->d_upper, e->upper_alloc_slots * node_partial_doubles(e));
+	e->upper_alloc_slots = 0;
+	int rc = dev_alloc(e, &e->d_upper, need * node_partial_doubles(e));
+	if (rc) return rc;
+	e->upper_alloc_slots = need;
+	return PHYAMD_OK;
+}
+
+int ensure_scaling_storage(phyamd_engine *e) {
+	if (e->d_lscale) return PHYAMD_OK;
+	return dev_alloc(e, &e->d_lscale, (size_t)(e->N - e->T) * e->P);
+}
+
+int check_ready(phyamd_engine *e) {
+	if (!e->have_topology) return fail(PHYAMD_EINVAL, "phyamd_set_topology has not been called");
+	if (!e->have_lengths) return fail(PHYAMD_EINVAL, "phyamd_set_branch_lengths has not been called");
+	if (!e->have_freqs) return fail(PHYAMD_EINVAL, "phyamd_set_frequencies has not been called");
+	if (!e->have_rates) return fail(PHYAMD_EINVAL, "phyamd_set_category_rates has not been called");
+	if (!e->have_weights) return fail(PHYAMD_EINVAL, "phyamd_set_pattern_weights has not been called");
+	for (int t = 0; t < e->T; t++)
+		if (!e->tip_set[t]) return fail(PHYAMD_EINVAL, "tip %d has no data (phyamd_set_tip_states / phyamd_set_tip_partials)", t);
+	if (!e->have_eigen) {
+		for (int n = 0; n < e->N; n++)
+			if (n != e->root && !e->explicit_host[n]) return fail(PHYAMD_EINVAL, "no eigen system and node %d has no explicit matrices", n);
+	}
+	return PHYAMD_OK;
+}
+
+int update_matrices(phyamd_engine *e) {
+	if (!e->matrices_dirty) return PHYAMD_OK;
+	if (e->have_eigen) {
+		const size_t total = (size_t)e->N * e->C * e->S * e->S;
+		const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+		hipLaunchKernelGGL(k_transition_matrices, dim3(blocks), dim3(256), 0, e->stream, e->S, e->C, e->N, e->d_model, e->d_rates, e->d_lengths,
+		                   e->d_explicit, e->root, e->d_mats, e->d_dmats);
+		HIP_TRY(hipGetLastError());
+	}
+	e->matrices_dirty = false;
+	return PHYAMD_OK;
+}
+
+dim3 block_dims(const phyamd_engine *e) { return dim3(WAVE, e->C, e->G); }
+
+template <bool SCALE>
+int launch_lower_levels(phyamd_engine *e) {
+	const int levels = (int)e->lower_level_off.size() - 1;
+	const size_t lds = sizeof(double) * ((size_t)4 * e->G * e->C * WAVE + e->G);
+	for (int lv = 0; lv < levels; lv++) {
+		const int off = e->lower_level_off[lv], cnt = e->lower_level_off[lv + 1] - off;
+		if (cnt == 0) continue;
+		const bool is_root = lv == levels - 1;
+		dim3 grid(e->nblk, cnt);
+		if (is_root)
+			hipLaunchKernelGGL((k_lower4<SCALE, true>), grid, block_dims(e), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->C, e->d_tipmask,
+			                   e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_lnl_part);
+		else
+			hipLaunchKernelGGL((k_lower4<SCALE, false>), grid, block_dims(e), SCALE ? lds : 0, e->stream, e->d_lower_ops + off, e->T, e->P, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_lnl_part);
+	}
+	HIP_TRY(hipGetLastError());
+	e->prof.lower_launches = levels;
+	return PHYAMD_OK;
+}
+
+int launch_lower(phyamd_engine *e) { return e->scaling_on ? launch_lower_levels<true>(e) : launch_lower_levels<false>(e); }
+
+template <bool SCALE, bool FOLD, bool COMPAT>
+int launch_upper_levels(phyamd_engine *e) {
+	const int levels = (int)e->upper_level_off.size() - 1;
+	const size_t lds = sizeof(double) * ((size_t)6 * e->G * e->C * WAVE + 2 * e->G * e->C);
+	for (int lv = 0; lv < levels; lv++) {
+		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
+		if (cnt == 0) continue;
+		dim3 grid(e->nblk, cnt);
+		hipLaunchKernelGGL((k_upper4<SCALE, FOLD, COMPAT>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C, e->d_tipmask,
+		                   e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_gpart, e->nblk);
+	}
+	HIP_TRY(hipGetLastError());
+	e->prof.upper_launches = levels;
+	return PHYAMD_OK;
+}
+
+int launch_upper(phyamd_engine *e, int flags) {
+	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS, compat = (flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on;
+	if (e->scaling_on) {
+		if (fold) return compat ? launch_upper_levels<true, true, true>(e) : launch_upper_levels<true, true, false>(e);
+		return compat ? launch_upper_levels<true, false, true>(e) : launch_upper_levels<true, false, false>(e);
+	}
+	return fold ? launch_upper_levels<false, true, false>(e) : launch_upper_levels<false, false, false>(e);
+}
+
+void record(phyamd_engine *e, int i) {
+	if (e->profiling) (void)hipEventRecord(e->ev[i], e->stream);
+}
+
+// lower pass (+ lazy rescaling).  On return d_result[0] holds lnL on the device.
+int run_lower(phyamd_engine *e, bool need_host_check) {
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	if ((rc = check_ready(e))) return rc;
+	record(e, 0);
+	if ((rc = update_matrices(e))) return rc;
+	record(e, 1);
+	if (e->scaling_on && (rc = ensure_scaling_storage(e))) return rc;
+	for (int attempt = 0; attempt < 2; attempt++) {
+		if ((rc = launch_lower(e))) return rc;
+		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->nblk, (const uint8_t *)nullptr, e->d_result);
+		HIP_TRY(hipGetLastError());
+		if (e->cfg.rescale != PHYAMD_RESCALE_AUTO || e->scaling_on || !need_host_check) break;
+		// lazy switch (treelikelihood.c:1496-1519): +-inf lnL turns rescaling on for good and recomputes
+		HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		if (!std::isinf(e->h_result[0])) break;
+		e->scaling_on = true;
+		if ((rc = ensure_scaling_storage(e))) return rc;
+	}
+	record(e, 2);
+	e->upper_valid = false;
+	return PHYAMD_OK;
+}
+
+int run_gradient(phyamd_engine *e, int flags) {
+	int rc;
+	if ((rc = run_lower(e, true))) return rc;
+	if ((rc = ensure_upper_storage(e))) return rc;
+	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
+	if ((rc = launch_upper(e, flags))) return rc;
+	record(e, 3);
+	hipLaunchKernelGGL(k_reduce_rows, dim3(e->N * e->C), dim3(64), 0, e->stream, e->d_gpart, e->nblk, e->d_row_valid, e->d_result + 1);
+	HIP_TRY(hipGetLastError());
+	record(e, 4);
+	e->upper_valid = true;
+	return PHYAMD_OK;
+}
+
+void finish_profile(phyamd_engine *e, bool with_upper) {
+	if (!e->profiling) return;
+	(void)hipEventSynchronize(e->ev[with_upper ? 4 : 2]);
+	float ms = 0;
+	(void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
+	e->prof.matrices_ms = ms;
+	(void)hipEventElapsedTime(&ms, e->ev[1], e->ev[2]);
+	e->prof.lower_ms = ms;
+	e->prof.upper_ms = e->prof.reduce_ms = 0;
+	if (with_upper) {
+		(void)hipEventElapsedTime(&ms, e->ev[2], e->ev[3]);
+		e->prof.upper_ms = ms;
+		(void)hipEventElapsedTime(&ms, e->ev[3], e->ev[4]);
+		e->prof.reduce_ms = ms;
+	}
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+const char *phyamd_last_error(void) { return g_last_error.c_str(); }
+int phyamd_abi_version(void) { return PHYAMD_ABI_VERSION; }
+
+int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
+	if (!cfg || !out) return fail(PHYAMD_EINVAL, "null argument");
+	*out = nullptr;
+	if (cfg->tip_count < 2) return fail(PHYAMD_EINVAL, "tip_count must be >= 2 (got %d)", cfg->tip_count);
+	if (cfg->pattern_count < 1) return fail(PHYAMD_EINVAL, "pattern_count must be >= 1 (got %d)", cfg->pattern_count);
+	if (cfg->category_count < 1) return fail(PHYAMD_EINVAL, "category_count must be >= 1 (got %d)", cfg->category_count);
+	if (cfg->state_count != 4) return fail(PHYAMD_EUNSUPPORTED, "state_count %d: only the 4-state kernels are built in this revision", cfg->state_count);
+	if (cfg->rescale < 0 || cfg->rescale > 2) return fail(PHYAMD_EINVAL, "rescale must be PHYAMD_RESCALE_*");
+	int ndev = 0;
+	HIP_TRY(hipGetDeviceCount(&ndev));
+	if (ndev == 0) return fail(PHYAMD_EDEVICE, "no HIP device visible");
+	phyamd_engine *e = new phyamd_engine();
+	e->cfg = *cfg;
+	e->T = cfg->tip_count;
+	e->N = 2 * e->T - 1;
+	e->P = cfg->pattern_count;
+	e->S = cfg->state_count;
+	e->C = cfg->category_count;
+	if (cfg->device >= 0) e->device = cfg->device;
+	else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+	if (e->device >= ndev) {
+		delete e;
+		return fail(PHYAMD_EINVAL, "device %d out of range (%d visible)", cfg->device, ndev);
+	}
+	auto bail = [&](int rc) {
+		phyamd_destroy(e);
+		return rc;
+	};
+	{
+		hipError_t err = hipSetDevice(e->device);
+		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "hipSetDevice(%d): %s", e->device, hipGetErrorString(err)));
+	}
+	if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
+	else {
+		hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(err)));
+		e->own_stream = true;
+	}
+	e->scaling_on = cfg->rescale == PHYAMD_RESCALE_ALWAYS;
+	if (e->C > MAX_WAVES) {
+		delete e;
+		return fail(PHYAMD_EUNSUPPORTED, "category_count %d exceeds %d (one wave per category)", cfg->category_count, MAX_WAVES);
+	}
+	e->G = std::max(1, 4 / e->C);  // at least 4 waves per workgroup
+	e->nblk = (e->P + WAVE * e->G * PPT - 1) / (WAVE * e->G * PPT);
+	e->tip_set.assign(e->T, 0);
+	e->explicit_host.assign(e->N, 0);
+	const size_t np = node_partial_doubles(e);
+	const size_t msz = (size_t)e->N * e->C * e->S * e->S;
+	if (cfg->max_device_bytes > 0) {
+		const double need = 8.0 * ((double)(e->N - e->T) * np + 2.0 * np) + (double)e->T * e->P;
+		if (need > (double)cfg->max_device_bytes)
+			return bail(fail(PHYAMD_ENOMEM, "engine needs >= %.3g bytes, max_device_bytes is %lld (pattern tiling is not built in this revision)", need,
+			                 (long long)cfg->max_device_bytes));
+	}
+	int rc;
+	if ((rc = dev_alloc(e, &e->d_tipmask, (size_t)e->T * e->P))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_lower, (size_t)(e->N - e->T) * np))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_mats, msz))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_dmats, msz))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_model, (size_t)e->S + 2 * e->S * e->S))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_Q, (size_t)e->S * e->S))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_freqs, (size_t)e->S))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_rates, (size_t)e->C))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_props, (size_t)e->C))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_lengths, (size_t)e->N))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_weights, (size_t)e->P))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_plk, (size_t)e->P))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)e->nblk))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_gpart, (size_t)e->N * e->C * e->nblk))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_result, (size_t)1 + e->N * e->C))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_explicit, (size_t)e->N))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_row_valid, (size_t)e->N * e->C))) return bail(rc);
+	{
+		hipError_t err = hipHostMalloc(reinterpret_cast<void **>(&e->h_result), sizeof(double) * ((size_t)1 + e->N * e->C), hipHostMallocDefault);
+		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "hipHostMalloc: %s", hipGetErrorString(err)));
+		err = hipMemsetAsync(e->d_explicit, 0, e->N, e->stream);
+		if (err == hipSuccess) err = hipMemsetAsync(e->d_gpart, 0, sizeof(double) * (size_t)e->N * e->C * e->nblk, e->stream);
+		if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "memset: %s", hipGetErrorString(err)));
+		for (auto &ev : e->ev) {
+			err = hipEventCreate(&ev);
+			if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "hipEventCreate: %s", hipGetErrorString(err)));
+		}
+	}
+	*out = e;
+	return PHYAMD_OK;
+}
+
+void phyamd_destroy(phyamd_engine *e) {
+	if (!e) return;
+	(void)hipSetDevice(e->device);
+	if (e->stream) (void)hipStreamSynchronize(e->stream);
+	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q,
+	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk,
+	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
+	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})
+		if (p) (void)hipFree(p);
+	if (e->h_result) (void)hipHostFree(e->h_result);
+	for (auto &ev : e->ev)
+		if (ev) (void)hipEventDestroy(ev);
+	if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+	delete e;
+}
+
+#define CHECK_ENGINE(e) \
+	if (!(e)) return fail(PHYAMD_EINVAL, "null engine")
+
+int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states) {
+	CHECK_ENGINE(e);
+	if (tip < 0 || tip >= e->T || !states) return fail(PHYAMD_EINVAL, "bad tip %d or null states", tip);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	std::vector<uint8_t> mask(e->P);
+	for (int k = 0; k < e->P; k++) mask[k] = states[k] < 4 ? (uint8_t)(1u << states[k]) : (uint8_t)0xF;  // code >= S: unknown (treelikelihood4.c:946-988)
+	HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->tip_set[tip] = 1;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
+	CHECK_ENGINE(e);
+	if (tip < 0 || tip >= e->T || !partials) return fail(PHYAMD_EINVAL, "bad tip %d or null partials", tip);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	std::vector<uint8_t> mask(e->P);
+	for (int k = 0; k < e->P; k++) {
+		unsigned m = 0;
+		for (int s = 0; s < 4; s++) {
+			const double v = partials[(size_t)k * 4 + s];
+			if (v == 1.0) m |= 1u << s;
+			else if (v != 0.0)
+				return fail(PHYAMD_EUNSUPPORTED, "tip %d pattern %d: tip partials other than 0/1 ambiguity masks are not built in this revision", tip, k);
+		}
+		mask[k] = (uint8_t)m;
+	}
+	HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->tip_set[tip] = 1;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_pattern_weights(phyamd_engine *e, const double *weights) {
+	CHECK_ENGINE(e);
+	if (!weights) return fail(PHYAMD_EINVAL, "null weights");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	HIP_TRY(hipMemcpyAsync(e->d_weights, weights, sizeof(double) * e->P, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->have_weights = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_topology(phyamd_engine *e, const int32_t *left, const int32_t *right, int root) {
+	CHECK_ENGINE(e);
+	if (!left || !right) return fail(PHYAMD_EINVAL, "null topology arrays");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	std::vector<int32_t> old_l = e->left, old_r = e->right;
+	const int old_root = e->root;
+	e->left.assign(left, left + e->N);
+	e->right.assign(right, right + e->N);
+	e->root = root;
+	if ((rc = build_schedule(e))) {
+		e->left = old_l;
+		e->right = old_r;
+		e->root = old_root;
+		if (e->have_topology) (void)build_schedule(e);
+		return rc;
+	}
+	if ((rc = upload_schedule(e))) return rc;
+	e->have_topology = true;
+	e->matrices_dirty = true;
+	e->upper_valid = false;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_branch_lengths(phyamd_engine *e, const double *lengths) {
+	CHECK_ENGINE(e);
+	if (!lengths) return fail(PHYAMD_EINVAL, "null lengths");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	e->lengths.assign(lengths, lengths + e->N);
+	if (e->have_topology) e->lengths[e->root] = 0.0;
+	HIP_TRY(hipMemcpyAsync(e->d_lengths, e->lengths.data(), sizeof(double) * e->N, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->have_lengths = true;
+	e->matrices_dirty = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_eigen(phyamd_engine *e, const double *eval, const double *evec, const double *ivec) {
+	CHECK_ENGINE(e);
+	if (!eval || !evec || !ivec) return fail(PHYAMD_EINVAL, "null eigen system");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	const int S = e->S;
+	e->model.resize((size_t)S + 2 * S * S);
+	std::copy(eval, eval + S, e->model.begin());
+	std::copy(evec, evec + S * S, e->model.begin() + S);
+	std::copy(ivec, ivec + S * S, e->model.begin() + S + S * S);
+	HIP_TRY(hipMemcpyAsync(e->d_model, e->model.data(), sizeof(double) * e->model.size(), hipMemcpyHostToDevice, e->stream));
+	// Q = evec diag(eval) ivec: the gradient kernels use (dP/dt) p = Q (P p)
+	std::vector<double> Q((size_t)S * S, 0.0);
+	for (int i = 0; i < S; i++)
+		for (int j = 0; j < S; j++) {
+			double q = 0.0;
+			for (int k = 0; k < S; k++) q += evec[i * S + k] * eval[k] * ivec[k * S + j];
+			Q[(size_t)i * S + j] = q;
+		}
+	HIP_TRY(hipMemcpyAsync(e->d_Q, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, e->stream));
+	e->have_Q = true;
+	std::fill(e->explicit_host.begin(), e->explicit_host.end(), 0);
+	HIP_TRY(hipMemsetAsync(e->d_explicit, 0, e->N, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->have_eigen = true;
+	e->matrices_dirty = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_frequencies(phyamd_engine *e, const double *freqs) {
+	CHECK_ENGINE(e);
+	if (!freqs) return fail(PHYAMD_EINVAL, "null freqs");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	e->freqs.assign(freqs, freqs + e->S);
+	HIP_TRY(hipMemcpyAsync(e->d_freqs, e->freqs.data(), sizeof(double) * e->S, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->have_freqs = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_category_rates(phyamd_engine *e, const double *rates, const double *proportions) {
+	CHECK_ENGINE(e);
+	if (!rates || !proportions) return fail(PHYAMD_EINVAL, "null rates/proportions");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	e->rates.assign(rates, rates + e->C);
+	e->props.assign(proportions, proportions + e->C);
+	HIP_TRY(hipMemcpyAsync(e->d_rates, e->rates.data(), sizeof(double) * e->C, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipMemcpyAsync(e->d_props, e->props.data(), sizeof(double) * e->C, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->have_rates = true;
+	e->matrices_dirty = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_set_node_matrices(phyamd_engine *e, int node, const double *matrices) {
+	CHECK_ENGINE(e);
+	if (node < 0 || node >= e->N || !matrices) return fail(PHYAMD_EINVAL, "bad node %d or null matrices", node);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	const size_t sz = (size_t)e->C * e->S * e->S;
+	HIP_TRY(hipMemcpyAsync(e->d_mats + (size_t)node * sz, matrices, sizeof(double) * sz, hipMemcpyHostToDevice, e->stream));
+	e->explicit_host[node] = 1;
+	HIP_TRY(hipMemcpyAsync(e->d_explicit + node, &e->explicit_host[node], 1, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return PHYAMD_OK;
+}
+
+int phyamd_set_rate_matrix(phyamd_engine *e, const double *Q) {
+	CHECK_ENGINE(e);
+	if (!Q) return fail(PHYAMD_EINVAL, "null Q");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	HIP_TRY(hipMemcpyAsync(e->d_Q, Q, sizeof(double) * e->S * e->S, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->have_Q = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_log_likelihood(phyamd_engine *e, double *lnl) {
+	CHECK_ENGINE(e);
+	if (!lnl) return fail(PHYAMD_EINVAL, "null lnl");
+	int rc;
+	if ((rc = run_lower(e, true))) return rc;
+	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	finish_profile(e, false);
+	*lnl = e->h_result[0];
+	return PHYAMD_OK;
+}
+
+int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out) {
+	CHECK_ENGINE(e);
+	if (!device_out) return fail(PHYAMD_EINVAL, "null device_out");
+	int rc;
+	if ((rc = run_gradient(e, flags))) return rc;
+	HIP_TRY(hipMemcpyAsync(device_out, e->d_result, sizeof(double) * ((size_t)1 + e->N * e->C), hipMemcpyDeviceToDevice, e->stream));
+	return PHYAMD_OK;
+}
+
+int phyamd_gradient(phyamd_engine *e, int flags, double *lnl, double *cat_gradient) {
+	CHECK_ENGINE(e);
+	if (!cat_gradient) return fail(PHYAMD_EINVAL, "null cat_gradient");
+	int rc;
+	if ((rc = run_gradient(e, flags))) return rc;
+	const size_t n = (size_t)1 + e->N * e->C;
+	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	finish_profile(e, true);
+	const double l = e->h_result[0];
+	if (lnl) *lnl = l;
+	if (std::isnan(l) || std::isinf(l)) {  // treelikelihood.c:327-332
+		for (size_t i = 0; i < n - 1; i++) cat_gradient[i] = NAN;
+	} else
+		std::memcpy(cat_gradient, e->h_result + 1, sizeof(double) * (n - 1));
+	return PHYAMD_OK;
+}
+
+int phyamd_branch_gradient(phyamd_engine *e, int flags, const double *rates_without_mu, double *lnl, double *branch_gradient) {
+	CHECK_ENGINE(e);
+	if (!branch_gradient) return fail(PHYAMD_EINVAL, "null branch_gradient");
+	std::vector<double> cg((size_t)e->N * e->C);
+	int rc;
+	if ((rc = phyamd_gradient(e, flags, lnl, cg.data()))) return rc;
+	const double *r = rates_without_mu ? rates_without_mu : e->rates.data();
+	for (int n = 0; n < e->N; n++) {  // gradient_branch_length_from_cat_inplace, treelikelihood.c:3129-3143
+		if (e->C == 1) {
+			branch_gradient[n] = cg[n];  // catCount == 1: no rate/weight factor (treelikelihood.c:3258-3266)
+			continue;
+		}
+		double g = cg[(size_t)n * e->C] * e->props[0] * r[0];
+		for (int c = 1; c < e->C; c++) g += cg[(size_t)n * e->C + c] * e->props[c] * r[c];
+		branch_gradient[n] = g;
+	}
+	return PHYAMD_OK;
+}
+
+int phyamd_synchronize(phyamd_engine *e) {
+	CHECK_ENGINE(e);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return PHYAMD_OK;
+}
+
+int phyamd_get_pattern_log_likelihoods(phyamd_engine *e, double *out) {
+	CHECK_ENGINE(e);
+	if (!out) return fail(PHYAMD_EINVAL, "null out");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	HIP_TRY(hipMemcpyAsync(out, e->d_plk, sizeof(double) * e->P, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return PHYAMD_OK;
+}
+
+int phyamd_get_partials(phyamd_engine *e, int node, int upper, double *out) {
+	CHECK_ENGINE(e);
+	if (!out || node < 0 || node >= e->N) return fail(PHYAMD_EINVAL, "bad node %d or null out", node);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	const size_t np = node_partial_doubles(e);
+	if (!upper) {
+		if (node < e->T) {  // rebuild the replicated tip partial from its mask
+			std::vector<uint8_t> mask(e->P);
+			HIP_TRY(hipMemcpyAsync(mask.data(), e->d_tipmask + (size_t)node * e->P, e->P, hipMemcpyDeviceToHost, e->stream));
+			HIP_TRY(hipStreamSynchronize(e->stream));
+			for (int c = 0; c < e->C; c++)
+				for (int k = 0; k < e->P; k++)
+					for (int s = 0; s < 4; s++) out[((size_t)c * e->P + k) * 4 + s] = (mask[k] >> s) & 1 ? 1.0 : 0.0;
+			return PHYAMD_OK;
+		}
+		HIP_TRY(hipMemcpyAsync(out, e->d_lower + (size_t)(node - e->T) * np, sizeof(double) * np, hipMemcpyDeviceToHost, e->stream));
+	} else {
+		if (!e->keep_partials || !e->upper_valid) return fail(PHYAMD_EINVAL, "upper partials need phyamd_set_keep_partials(1) before phyamd_gradient");
+		if (node == e->root) return fail(PHYAMD_EINVAL, "the root has no upper partial");
+		HIP_TRY(hipMemcpyAsync(out, e->d_upper + (size_t)e->upper_slot[node] * np, sizeof(double) * np, hipMemcpyDeviceToHost, e->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return PHYAMD_OK;
+}
+
+int phyamd_get_node_matrices(phyamd_engine *e, int node, int derivative, double *out) {
+	CHECK_ENGINE(e);
+	if (!out || node < 0 || node >= e->N) return fail(PHYAMD_EINVAL, "bad node %d or null out", node);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	if ((rc = check_ready(e))) return rc;
+	if ((rc = update_matrices(e))) return rc;
+	const size_t sz = (size_t)e->C * e->S * e->S;
+	HIP_TRY(hipMemcpyAsync(out, (derivative ? e->d_dmats : e->d_mats) + (size_t)node * sz, sizeof(double) * sz, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return PHYAMD_OK;
+}
+
+int phyamd_is_rescaling(phyamd_engine *e) {
+	CHECK_ENGINE(e);
+	return e->scaling_on ? 1 : 0;
+}
+
+int phyamd_set_keep_partials(phyamd_engine *e, int on) {
+	CHECK_ENGINE(e);
+	const bool want = on != 0;
+	if (want == e->keep_partials) return PHYAMD_OK;
+	e->keep_partials = want;
+	e->upper_valid = false;
+	if (e->have_topology) {
+		int rc;
+		if ((rc = bind_device(e))) return rc;
+		if ((rc = build_schedule(e))) return rc;
+		if ((rc = upload_schedule(e))) return rc;
+	}
+	return PHYAMD_OK;
+}
+
+int phyamd_set_profiling(phyamd_engine *e, int on) {
+	CHECK_ENGINE(e);
+	e->profiling = on != 0;
+	return PHYAMD_OK;
+}
+
+int phyamd_get_profile(phyamd_engine *e, phyamd_profile *out) {
+	CHECK_ENGINE(e);
+	if (!out) return fail(PHYAMD_EINVAL, "null out");
+	e->prof.device_bytes = e->device_bytes;
+	e->prof.tiles = 1;
+	*out = e->prof;
+	return PHYAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the reference's golden vectors and the CPU oracle.
+
+Tolerances: lnL 1e-10 relative; per-pattern lnL 1e-11 (+1e-11 abs); partials 1e-9 relative;
+gradient 1e-9 * max(1, |g|_inf).
+"""
+import numpy as np
+import pytest
+
+from golden_util import UNROOTED_CASES, load, oracle_problem, read_spec
+from gpu_util import engine_from_problem, random_problem
+from oracle import phyoracle as po
+from physher_amd.engine import GRAD_COMPAT_SCALED, GRAD_FOLD_ROOT_FREQS, RESCALE_ALWAYS, RESCALE_AUTO, RESCALE_NEVER, Engine, EngineError
+
+pytestmark = pytest.mark.gpu
+
+CASES4 = [c for c in UNROOTED_CASES if read_spec(c)["datatype"] == "nucleotide"]
+
+
+def _tip_mode(case):
+    return "states" if read_spec(case)["tipstates"] == "1" else "partials"
+
+
+def _rescale(case):
+    return RESCALE_ALWAYS if read_spec(case)["rescale"] == "1" else RESCALE_AUTO
+
+
+def _grad_tol(ref):
+    return 1e-9 * max(1.0, np.abs(ref[np.isfinite(ref)]).max())
+
+
+@pytest.mark.parametrize("case", CASES4)
+def test_golden_log_likelihood(case):
+    gold = load(case)
+    pb = oracle_problem(case, gold)
+    with engine_from_problem(pb, rescale=_rescale(case), tip_mode=_tip_mode(case)) as e:
+        lnl = e.log_likelihood()
+        assert e.rescaling == gold["rescaled"]
+        assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+        np.testing.assert_allclose(e.pattern_log_likelihoods(), gold["pattern_lk"], rtol=1e-11, atol=1e-11)
+        if "partials_root" in gold:
+            np.testing.assert_allclose(e.partials(gold["root"]), gold["partials_root"], rtol=1e-9, atol=1e-300)
+            np.testing.assert_allclose(e.partials(gold["tip_count"]), gold["partials_first_internal"], rtol=1e-9, atol=1e-300)
+        if "pt" in gold:
+            for q, node in enumerate(gold["pt_nodes"]):
+                np.testing.assert_allclose(e.node_matrices(node), gold["pt"][q], rtol=1e-12, atol=1e-15)
+                np.testing.assert_allclose(e.node_matrices(node, derivative=True), gold["dpt"][q], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("case", CASES4)
+@pytest.mark.parametrize("fold", [0, 1])
+def test_golden_branch_gradient(case, fold):
+    """fold=1 / COMPAT reproduce the reference's two quirks (see tests/test_oracle_golden.py); fold=0 is the default."""
+    gold = load(case)
+    N = gold["node_count"]
+    if not fold and not (gold["gradient_all_flags"] & 4):
+        pytest.skip("reference never runs include_root_freqs = false for this model")
+    ref = gold["gradient_tree"] if fold else gold["gradient_all"][:N]
+    pb = oracle_problem(case, gold)
+    flags = (GRAD_FOLD_ROOT_FREQS if fold else 0) | (GRAD_COMPAT_SCALED if gold["rescaled"] and gold["category_count"] > 1 else 0)
+    with engine_from_problem(pb, rescale=_rescale(case), tip_mode=_tip_mode(case)) as e:
+        e.set_keep_partials(True)
+        lnl, cg = e.gradient(flags)
+        assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+        g = po.branch_gradient_from_cat(cg, gold["cat_rates"], gold["cat_proportions"], zero_node=gold["right"][gold["root"]])
+        finite = np.isfinite(ref)
+        assert np.abs(g[finite] - ref[finite]).max() <= _grad_tol(ref)
+        # the C-ABI epilogue gives the same numbers (root->right is not zeroed there: that is the caller's convention)
+        lnl2, bg = e.branch_gradient(flags)
+        keep = finite.copy()
+        keep[gold["right"][gold["root"]]] = False
+        assert np.abs(bg[keep] - ref[keep]).max() <= _grad_tol(ref)
+        if fold and "upper_first_internal" in gold and not gold["rescaled"]:
+            np.testing.assert_allclose(e.partials(gold["tip_count"], upper=True), gold["upper_first_internal"], rtol=1e-9, atol=1e-300)
+
+
+def _compare_with_oracle(pb, rescale, flags=0, tip_mode="states", check_partials=False):
+    ref = pb.gradient(want_partials=check_partials)
+    with engine_from_problem(pb, rescale=rescale, tip_mode=tip_mode) as e:
+        if check_partials:
+            e.set_keep_partials(True)
+        lnl_only = e.log_likelihood()
+        lnl, cg = e.gradient(flags)
+        assert lnl == lnl_only  # fixed-order reductions: bitwise reproducible
+        assert e.rescaling == ref["rescaled"]
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        np.testing.assert_allclose(e.pattern_log_likelihoods(), ref["pattern_lk"], rtol=1e-11, atol=1e-11)
+        tol = 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+        assert np.abs(cg - ref["cat_grad"]).max() <= tol
+        if check_partials:
+            for n in range(pb.T, pb.N):
+                np.testing.assert_allclose(e.partials(n), ref["lower"][n], rtol=1e-9, atol=1e-300)
+            if not ref["rescaled"]:
+                for n in range(pb.N):
+                    if n != pb.root:
+                        np.testing.assert_allclose(e.partials(n, upper=True), ref["upper"][n], rtol=1e-9, atol=1e-300)
+        return lnl, cg
+
+
+@pytest.mark.parametrize("T,P,C", [(2, 1, 1), (3, 63, 1), (5, 64, 2), (8, 65, 3), (16, 1000, 4), (33, 257, 5), (12, 129, 6), (9, 300, 8),
+                                   (10, 77, 16)])
+def test_against_oracle_shapes(T, P, C):
+    """ragged pattern counts (not multiples of the wave / workgroup), every category count incl. the 16-wave maximum"""
+    pb = random_problem(T, P, C, seed=100 + T + P + C)
+    _compare_with_oracle(pb, RESCALE_NEVER, check_partials=True)
+
+
+@pytest.mark.parametrize("shape", ["caterpillar", "balanced", "random"])
+def test_against_oracle_tree_shapes(shape):
+    pb = random_problem(40, 500, 4, seed=7, shape=shape, gaps=0.03)
+    _compare_with_oracle(pb, RESCALE_NEVER, check_partials=True)
+
+
+def test_against_oracle_fold_flag():
+    pb = random_problem(20, 300, 4, seed=9, fold_root_freqs=1)
+    _compare_with_oracle(pb, RESCALE_NEVER, flags=GRAD_FOLD_ROOT_FREQS)
+
+
+@pytest.mark.parametrize("C", [1, 4])
+def test_against_oracle_forced_rescaling(C):
+    pb = random_problem(150, 200, C, seed=11, bl=(0.3, 0.9), rescale=1)
+    _compare_with_oracle(pb, RESCALE_ALWAYS, check_partials=True)
+    pb.compat_scaled_gradient = 1
+    _compare_with_oracle(pb, RESCALE_ALWAYS, flags=GRAD_COMPAT_SCALED)
+
+
+def test_lazy_rescaling_switch():
+    """+-inf lnL without rescaling turns it on for good and recomputes (treelikelihood.c:1496-1519)."""
+    pb = random_problem(900, 64, 4, seed=13, bl=(0.5, 1.5), rescale=2)
+    ref = pb.gradient()
+    assert ref["rescaled"] and np.isfinite(ref["lnl"])
+    with engine_from_problem(pb, rescale=RESCALE_AUTO) as e:
+        assert not e.rescaling
+        lnl, cg = e.gradient()
+        assert e.rescaling
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        assert np.abs(cg - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:  # in-band failure like the reference: -inf and NaN gradient
+        lnl, cg = e.gradient()
+        assert np.isinf(lnl) and lnl < 0 and np.all(np.isnan(cg))
+
+
+def test_medium_problem_and_shard_additivity():
+    """cfg2-like shape at reduced size vs the oracle, then the sharding property used for multi-GPU:
+    lnL and the per-category gradient are sums over disjoint pattern shards."""
+    pb = random_problem(120, 6000, 4, seed=21)
+    lnl, cg = _compare_with_oracle(pb, RESCALE_NEVER)
+    cut = 2500
+    parts = []
+    for sl in (slice(0, cut), slice(cut, pb.P)):
+        sub = po.Problem(pb.left, pb.right, pb.root, pb.weights[sl], pb.eval, pb.evec, pb.ivec, pb.freqs, pb.cat_rates, pb.cat_props,
+                         pb.branch_lengths, tip_states=pb.tip_states[:, sl])
+        with engine_from_problem(sub, rescale=RESCALE_NEVER) as e:
+            parts.append(e.gradient())
+    assert abs(parts[0][0] + parts[1][0] - lnl) <= 1e-11 * abs(lnl)
+    assert np.abs(parts[0][1] + parts[1][1] - cg).max() <= 1e-10 * max(1.0, np.abs(cg).max())
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] shape (500 taxa x 1e5 patterns x 4 states x 4 categories) -- too big for the oracle in
+    seconds, so size-independent properties: determinism, weight linearity, duplicated-pattern invariance,
+    gradient vs central finite differences of lnL."""
+    from physher_amd import synth
+    rng = np.random.default_rng(5)
+    T, P, C = 500, 100_000, 4
+    tree = synth.random_tree(T, rng)
+    states, weights = synth.distinct_patterns(tree, P, 4, rng)
+    pb = random_problem(T, 8, C, seed=5)  # borrow a model
+    with Engine(T, P, 4, C, rescale=RESCALE_AUTO) as e:
+        e.set_topology(tree.left, tree.right, tree.root)
+        e.set_branch_lengths(tree.length)
+        e.set_eigen(pb.eval, pb.evec, pb.ivec)
+        e.set_frequencies(pb.freqs)
+        e.set_category_rates(pb.cat_rates, pb.cat_props)
+        e.set_pattern_weights(weights)
+        for t in range(T):
+            e.set_tip_states(t, states[t])
+        lnl, cg = e.gradient()
+        lnl2, cg2 = e.gradient()
+        assert lnl == lnl2 and np.array_equal(cg, cg2)
+        plk = e.pattern_log_likelihoods()
+        assert abs(np.dot(plk, weights) - lnl) <= 1e-11 * abs(lnl)
+        # linearity in the weights
+        e.set_pattern_weights(2.0 * weights)
+        lnl3, cg3 = e.gradient()
+        assert abs(lnl3 - 2 * lnl) <= 1e-12 * abs(lnl) and np.abs(cg3 - 2 * cg).max() <= 1e-11 * np.abs(cg).max()
+        e.set_pattern_weights(weights)
+        # finite differences on a few branches
+        bg = po.branch_gradient_from_cat(cg, pb.cat_rates, pb.cat_props)
+        for n in rng.choice([i for i in range(2 * T - 1) if i != tree.root], size=3, replace=False):
+            h = 1e-6
+            bl = tree.length.copy(); bl[n] += h
+            e.set_branch_lengths(bl); up = e.log_likelihood()
+            bl[n] -= 2 * h
+            e.set_branch_lengths(bl); dn = e.log_likelihood()
+            fd = (up - dn) / (2 * h)
+            assert abs(fd - bg[n]) <= 1e-4 * max(1.0, abs(bg[n])), (n, fd, bg[n])
+        e.set_branch_lengths(tree.length)
+
+
+def test_error_behaviour():
+    with Engine(4, 10, 4, 2) as e:
+        with pytest.raises(EngineError) as ei:
+            e.log_likelihood()
+        assert "topology" in str(ei.value)
+        with pytest.raises(EngineError):
+            e.set_topology([-1, -1, -1, -1, 0, 1, 2], [-1, -1, -1, -1, 1, 2, 3], 6)  # node 1 and 2 with two parents
+        e.set_topology([-1, -1, -1, -1, 0, 4, 5], [-1, -1, -1, -1, 1, 2, 3], 6)
+        with pytest.raises(EngineError) as ei:
+            e.log_likelihood()
+        assert "branch_lengths" in str(ei.value)
+    with pytest.raises(EngineError):
+        Engine(4, 10, 4, 17)  # more categories than waves in a workgroup
+    with pytest.raises(EngineError) as ei:
+        Engine(4, 10, 20, 4)
+    assert ei.value.code == -4  # loud, not a silent CPU fallback
+
+
+def test_explicit_matrices_jc69():
+    """Closed-form models hand P(t) matrices and Q to the engine instead of an eigen system."""
+    gold = load("jc69_t12")
+    pb = oracle_problem("jc69_t12", gold)
+    with engine_from_problem(pb, rescale=RESCALE_NEVER, tip_mode="partials") as e:
+        lnl_eig, cg_eig = e.gradient()
+    with Engine(pb.T, pb.P, 4, 1, rescale=RESCALE_NEVER) as e:
+        e.set_topology(pb.left, pb.right, pb.root)
+        e.set_branch_lengths(pb.branch_lengths)
+        e.set_frequencies(pb.freqs)
+        e.set_category_rates(pb.cat_rates, pb.cat_props)
+        e.set_pattern_weights(pb.weights)
+        for t in range(pb.T):
+            e.set_tip_states(t, pb.tip_states[t])
+        for n in range(pb.N):
+            if n == pb.root:
+                continue
+            t = pb.branch_lengths[n]
+            ex = np.exp(-4.0 / 3.0 * t)  # jc69.c:73-79
+            Pm = np.full((4, 4), 0.25 - 0.25 * ex) + np.eye(4) * ex
+            e.set_node_matrices(n, Pm[None])
+        with pytest.raises(EngineError):
+            e.gradient()  # no rate matrix yet
+        Q = np.full((4, 4), 1.0 / 3.0) - np.eye(4) * (4.0 / 3.0)
+        e.set_rate_matrix(Q)
+        lnl, cg = e.gradient()
+    assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+    assert np.abs(cg - cg_eig).max() <= 1e-9 * max(1.0, np.abs(cg_eig).max())
