@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Benchmark of the tree-likelihood hot path: lnL + branch-length-gradient evaluations per second.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1: launched by torch.distributed.run, one
+rank per GPU).  A step is one FULL re-evaluation, the protocol of the reference's own harness
+(examples/benchmarking.c:498-503): every branch's P(t) is rebuilt from the eigen system, then the
+post-order pass, the pre-order pass and the gradient are recomputed; the result (lnL and the
+per-branch gradient) ends up on the host.  Inputs (tip states, weights) are resident in HBM before the
+timed region.  With N > 1 the site patterns are sharded across ranks and one RCCL all-reduce of the
+[lnL, gradient] vector joins them (strong scaling: the workload is the same 1e6 patterns for every N).
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the `roofline` and `cpu_baseline` objects).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+GTR_RATES = (1.2, 3.1, 0.7, 0.9, 2.8, 1.0)  # ac ag at cg ct gt
+GTR_FREQS = (0.3, 0.2, 0.2, 0.3)
+ALPHA = 0.5
+# the usual discrete-gamma(alpha = 0.5) 4-category rates (mean 1); the engine takes rates as inputs, so the
+# benchmark needs no host-side quantile code
+GAMMA4_RATES_05 = (0.03338775, 0.25191592, 0.82026848, 2.89442785)
+
+
+def gtr_eigen():
+    """Eigen system of the normalised GTR rate matrix (host-side numpy; O(1) work, outside the timed region)."""
+    pi = np.array(GTR_FREQS)
+    ac, ag, at, cg, ct, gt = GTR_RATES
+    r = np.array([[0, ac, ag, at], [ac, 0, cg, ct], [ag, cg, 0, gt], [at, ct, gt, 0]], dtype=np.float64)
+    Q = r * pi[None, :]
+    np.fill_diagonal(Q, -Q.sum(axis=1))
+    Q /= -(pi * np.diag(Q)).sum()
+    d = np.sqrt(pi)
+    B = (d[:, None] * Q) / d[None, :]
+    w, V = np.linalg.eigh(0.5 * (B + B.T))
+    return w, V / d[:, None], V.T * d[None, :]
+
+
+def evolve_on_device(tree, site_count, seed, device):
+    """Sequences for every tip, evolved down the tree on the GPU (JC-style, 4 states).  uint8 [T][sites] torch tensor."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    N = tree.node_count
+    seqs = [None] * N
+    seqs[tree.root] = torch.randint(0, 4, (site_count,), dtype=torch.uint8, device=device, generator=g)
+    for n in range(N - 1, -1, -1):
+        if tree.left[n] < 0:
+            continue
+        for c in (int(tree.left[n]), int(tree.right[n])):
+            p_same = 0.25 + 0.75 * np.exp(-4.0 / 3.0 * tree.length[c])
+            change = torch.rand(site_count, device=device, generator=g) >= p_same
+            new = torch.randint(0, 4, (site_count,), dtype=torch.uint8, device=device, generator=g)
+            seqs[c] = torch.where(change, new, seqs[n])
+        seqs[n] = None
+    return torch.stack(seqs[: tree.tip_count])
+
+
+def algorithmic_bytes(T, P, C, S):
+    """SURVEY.md 8(d) three-pass accounting, split per kernel family."""
+    B = 8.0 * P * C * S
+    lower = (2 * T - 3) * B + T * P
+    upper_grad = (8 * T - 12) * B + 2 * T * P + 16 * (T - 1) * P
+    return lower, upper_grad
+
+
+def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
+    """Time the CPU path on a bounded sample (the first `sample_patterns` patterns) of the same workload.
+
+    Preferred: the compiled reference itself (oracle/_ref/ref_driver: physher's SSE kernels, 1 thread, the protocol
+    of examples/benchmarking.c).  Fallback: this repository's CPU port (oracle/libphyoracle.so).  The measured
+    per-evaluation time is scaled linearly in the pattern count (the cost is linear in patterns).
+    """
+    from physher_amd import synth
+    T = tree.tip_count
+    sp = min(sample_patterns, states.shape[1])
+    driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    sub = states[:, :sp]
+    if os.path.exists(driver):
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "aln.fa"), "w") as f:
+                f.write(synth.to_fasta(tree.names, sub, "nucleotide"))
+            with open(os.path.join(d, "tree.nwk"), "w") as f:
+                f.write(tree.newick() + "\n")
+            with open(os.path.join(d, "spec.txt"), "w") as f:
+                f.write(f"fasta {d}/aln.fa\nnewick {d}/tree.nwk\ndatatype nucleotide\nmodel gtr\n"
+                        f"rates {','.join(map(str, GTR_RATES[:5]))}\nfreqs {','.join(map(str, GTR_FREQS))}\n"
+                        f"categories {len(cat_rates)}\nalpha {ALPHA}\ntipstates 0\nsse 1\n")
+            # one gradient evaluation costs ~26 ns per (branch, pattern, category) on a 2 GHz core
+            est = 26e-9 * (2 * T - 2) * sp * len(cat_rates) * 1.3
+            iters = max(1, min(10, int(budget_s / (2.5 * est))))
+            try:
+                out = subprocess.run([driver, "bench", os.path.join(d, "spec.txt"), str(iters), "1"], capture_output=True, text=True,
+                                     timeout=max(120, 20 * budget_s), check=True).stdout
+                r = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+                compressed = r["patterns"]
+                t_eval = r["grad_ms_per_eval"] / 1e3
+                return dict(kind="reference", cores=1, t_eval=t_eval, patterns=compressed, iters=iters, lnl_ms=r["lnl_ms_per_eval"],
+                            sample=f"physher SSE path (oracle/_ref/ref_driver bench), {T} taxa x {compressed} patterns "
+                                   f"(first {sp} sites of the workload), {iters} gradient evals after 1 warm-up, scaled linearly to the full pattern count")
+            except Exception as exc:  # fall through to the port, but say why
+                print(f"[bench] reference driver failed ({exc}); timing the CPU port instead", file=sys.stderr)
+    from oracle import phyoracle as po
+    ev, U, Ui = gtr_eigen()
+    pb = po.Problem(tree.left, tree.right, tree.root, weights[:sp], ev, U, Ui, GTR_FREQS, cat_rates, np.full(len(cat_rates), 1.0 / len(cat_rates)),
+                    tree.length, tip_states=np.ascontiguousarray(sub))
+    t0 = time.perf_counter()
+    pb.gradient()
+    t_eval = time.perf_counter() - t0
+    return dict(kind="port", cores=1, t_eval=t_eval, patterns=sp, iters=1, lnl_ms=None,
+                sample=f"scalar CPU port (oracle/phyoracle.c), {T} taxa x {sp} patterns, 1 evaluation, scaled linearly")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--taxa", type=int, default=1000)
+    ap.add_argument("--patterns", type=int, default=1_000_000)
+    ap.add_argument("--categories", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample-patterns", type=int, default=2000)
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run of this workload")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from physher_amd import synth
+    from physher_amd.engine import RESCALE_AUTO, Engine
+
+    T, P, C = args.taxa, args.patterns, args.categories
+    rng = np.random.default_rng(args.seed)
+    tree = synth.random_tree(T, rng)  # identical on every rank
+    # contiguous shard of the pattern list; generated block-wise so the data do not depend on N
+    lo, hi = rank * P // world, (rank + 1) * P // world
+    BLK = 125_000
+    chunks = []
+    for b0 in range(0, P, BLK):
+        b1 = min(P, b0 + BLK)
+        if b1 <= lo or b0 >= hi:
+            continue
+        blk = evolve_on_device(tree, b1 - b0, args.seed * 100003 + b0, device)
+        chunks.append(blk[:, max(lo, b0) - b0: min(hi, b1) - b0].cpu().numpy())
+    states = np.ascontiguousarray(np.concatenate(chunks, axis=1))
+    del chunks
+    torch.cuda.empty_cache()
+    Pl = hi - lo
+    wrng = np.random.default_rng(args.seed + 17)
+    weights_all = wrng.integers(1, 4, size=P).astype(np.float64)
+    weights = weights_all[lo:hi]
+    if C == 4:
+        cat_rates = np.array(GAMMA4_RATES_05)
+        cat_rates = cat_rates / cat_rates.mean()
+    else:
+        cat_rates = np.linspace(0.2, 1.8, C) if C > 1 else np.ones(1)
+        cat_rates = cat_rates / cat_rates.mean()
+    cat_props = np.full(C, 1.0 / C)
+    ev, U, Ui = gtr_eigen()
+
+    stream = torch.cuda.current_stream(device)
+    eng = Engine(T, Pl, 4, C, device=local_rank, rescale=RESCALE_AUTO, stream=stream.cuda_stream)
+    eng.set_topology(tree.left, tree.right, tree.root)
+    eng.set_branch_lengths(tree.length)
+    eng.set_eigen(ev, U, Ui)
+    eng.set_frequencies(GTR_FREQS)
+    eng.set_category_rates(cat_rates, cat_props)
+    eng.set_pattern_weights(weights)
+    for t in range(T):
+        eng.set_tip_states(t, states[t])
+    eng.set_profiling(True)
+
+    N = 2 * T - 1
+    result = torch.zeros(1 + N * C, dtype=torch.float64, device=device)
+    host = torch.empty(1 + N * C, dtype=torch.float64, pin_memory=True)
+
+    def step():
+        eng.set_branch_lengths(tree.length)  # invalidates every P(t): full recompute (benchmarking.c:498-500)
+        eng.gradient_device(result.data_ptr())
+        if world > 1:
+            dist.all_reduce(result)
+        host.copy_(result, non_blocking=False)
+        r = host.numpy()
+        cg = r[1:].reshape(N, C)
+        bg = (cg * (cat_props * cat_rates)[None, :]).sum(axis=1) if C > 1 else cg[:, 0]  # treelikelihood.c:3129-3143
+        return float(r[0]), bg
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        lnl, bg = step()
+    fence()
+    prof = dict(lower_ms=0.0, upper_ms=0.0, matrices_ms=0.0, reduce_ms=0.0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lnl, bg = step()
+        p = eng.profile()  # HIP-event times of this evaluation, recorded on the engine's stream
+        for k in prof:
+            prof[k] += p[k]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    for k in prof:
+        prof[k] /= max(1, args.steps)
+    p = eng.profile()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = args.steps / elapsed
+        lower_b, upper_b = algorithmic_bytes(T, Pl, C, 4)  # this rank's shard
+        launches = max(1, p["upper_launches"])
+        achieved = upper_b / (prof["upper_ms"] * 1e-3) / 1e9 if prof["upper_ms"] > 0 else None
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                with open(args.traffic_json) as f:
+                    tj = json.load(f)
+                if tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C:
+                    traffic = tj["upper_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "lnL+gradient evals/sec, 1000-taxon GTR+G4 fp64, 1e6 site patterns",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"GTR+G{C} DNA, {T} taxa x {P} patterns x 4 states x {C} categories, unrooted, full recompute per eval "
+                                   f"(BASELINE configs[4] shape; {Pl} patterns on this rank)",
+                       "taxa": T, "patterns": P, "categories": C, "states": 4, "patterns_per_gpu": Pl, "lnL": lnl,
+                       "rescaling": eng.rescaling, "device_bytes": p["device_bytes"]},
+            "roofline": {"bound": "hbm", "kernel": "k_upper4 (pre-order pass + fused branch gradient)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": upper_b / launches, "launches_per_eval": launches,
+                         "avg_launch_ms": prof["upper_ms"] / launches,
+                         "lower_kernel": {"kernel": "k_lower4", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
+                                          "launches_per_eval": p["lower_launches"], "ms_per_eval": prof["lower_ms"]},
+                         "ms_per_eval": {k: prof[k] for k in prof}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(tree, states, weights, cat_rates, args.cpu_sample_patterns, args.cpu_budget_s)
+            scaled = cb["t_eval"] * (P / cb["patterns"])
+            out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "evals/s", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+                                   "sample_seconds_per_eval": cb["t_eval"], "sample_patterns": cb["patterns"]}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(MAX_WAVES *WAVE) void k_upper4(const NodeOp *__rest
                                                             double *__restrict__ upper, const double *__restrict__ mats,
                                                             const double *__restrict__ Q, const double *__restrict__ freqs,
                                                             const double *__restrict__ props, const double *__restrict__ weights,
-                                                            double *__restrict__ gpart, int nblk) {
+                                                            const double *__restrict__ pattern_lk, double *__restrict__ gpart, int nblk) {
 	extern __shared__ double sh[];
 	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
@@ -293,7 +293,9 @@ __global__ __launch_bounds__(MAX_WAVES *WAVE) void k_upper4(const NodeOp *__rest
 		double D = 0.0;
 		for (int cc = 0; cc < C; cc++) D += xb[(g * C + cc) * WAVE + lane];
 		const double w = valid ? weights[k] : 0.0;
-		const double d = (SCALE && COMPAT) ? den : D;
+		// FOLD without rescaling is the reference's include_root_freqs = true arithmetic: it divides by exp(lnL_k)
+		// (treelikelihood.c:3207-3210), which for non-uniform pi is NOT the branch-local mixture sum D.
+		const double d = (SCALE && COMPAT) ? den : ((FOLD && !SCALE) ? exp(pattern_lk[k]) : D);
 		gl += w * numl / d;
 		gr += w * numr / d;
 		if (SCALE) {  // uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796); the factors cancel in num/den
@@ -370,6 +372,7 @@ struct phyamd_engine {
 	bool keep_partials = false;
 	bool profiling = false;
 	bool upper_valid = false;
+	bool prof_pending = false, prof_with_upper = false;
 
 	// schedule
 	std::vector<NodeOp> lower_ops, upper_ops;
@@ -603,7 +606,7 @@ int launch_upper_levels(phyamd_engine *e) {
 		if (cnt == 0) continue;
 		dim3 grid(e->nblk, cnt);
 		hipLaunchKernelGGL((k_upper4<SCALE, FOLD, COMPAT>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C, e->d_tipmask,
-		                   e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_gpart, e->nblk);
+		                   e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_gpart, e->nblk);
 	}
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = levels;
@@ -645,6 +648,8 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 		if ((rc = ensure_scaling_storage(e))) return rc;
 	}
 	record(e, 2);
+	e->prof_pending = e->profiling;
+	e->prof_with_upper = false;
 	e->upper_valid = false;
 	return PHYAMD_OK;
 }
@@ -659,12 +664,14 @@ int run_gradient(phyamd_engine *e, int flags) {
 	hipLaunchKernelGGL(k_reduce_rows, dim3(e->N * e->C), dim3(64), 0, e->stream, e->d_gpart, e->nblk, e->d_row_valid, e->d_result + 1);
 	HIP_TRY(hipGetLastError());
 	record(e, 4);
+	e->prof_with_upper = true;
 	e->upper_valid = true;
 	return PHYAMD_OK;
 }
 
 void finish_profile(phyamd_engine *e, bool with_upper) {
-	if (!e->profiling) return;
+	if (!e->profiling || !e->prof_pending) return;
+	e->prof_pending = false;
 	(void)hipEventSynchronize(e->ev[with_upper ? 4 : 2]);
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, e->ev[0], e->ev[1]);
@@ -1107,6 +1114,7 @@ int phyamd_set_profiling(phyamd_engine *e, int on) {
 int phyamd_get_profile(phyamd_engine *e, phyamd_profile *out) {
 	CHECK_ENGINE(e);
 	if (!out) return fail(PHYAMD_EINVAL, "null out");
+	finish_profile(e, e->prof_with_upper);  // waits for the last evaluation's events if they are still pending
 	e->prof.device_bytes = e->device_bytes;
 	e->prof.tiles = 1;
 	*out = e->prof;
