@@ -166,7 +166,7 @@ def main():
     tree = synth.random_tree(T, rng)  # identical on every rank
     # contiguous shard of the pattern list; generated block-wise so the data do not depend on N
     lo, hi = rank * P // world, (rank + 1) * P // world
-    BLK = 125_000
+    BLK = int(os.environ.get("PHYAMD_BENCH_BLOCK", "125000"))  # profiling runs use one big block: fewer generator kernels
     chunks = []
     for b0 in range(0, P, BLK):
         b1 = min(P, b0 + BLK)

@@ -89,8 +89,13 @@ __device__ __forceinline__ d4 mask4(unsigned m) {
 	return d4{(m & 1u) ? 1.0 : 0.0, (m & 2u) ? 1.0 : 0.0, (m & 4u) ? 1.0 : 0.0, (m & 8u) ? 1.0 : 0.0};
 }
 
+// Pointer into the AMDGPU constant address space: loads through it with a wave-uniform address become
+// s_load_dwordx* into SGPRs (kernel inputs that no kernel of the same launch writes: matrices, Q, pi, weights).
+typedef const __attribute__((address_space(4))) double *cptr;
+__device__ __forceinline__ cptr as_const(const double *p) { return (cptr)p; }
+
 // y = M v, M row-major 4x4 at a wave-uniform address (scalar loads)
-__device__ __forceinline__ d4 matvec4(const double *__restrict__ M, const d4 &v) {
+__device__ __forceinline__ d4 matvec4(cptr M, const d4 &v) {
 	d4 r;
 	r.x = M[0] * v.x + M[1] * v.y + M[2] * v.z + M[3] * v.w;
 	r.y = M[4] * v.x + M[5] * v.y + M[6] * v.z + M[7] * v.w;
@@ -114,7 +119,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // pattern-group loop; without this LLVM hoists all of them out of the loop, runs out of SGPRs and
 // parks them in VGPR lanes (v_writelane/v_readlane pairs around every use).  Re-issuing the scalar
 // loads per group costs a few s_load_dwordx16 from the scalar cache instead.
-__device__ __forceinline__ const double *opaque(const double *p) {
+__device__ __forceinline__ cptr opaque(cptr p) {
 	asm volatile("" : "+s"(p));
 	return p;
 }
@@ -156,21 +161,21 @@ __global__ void k_transition_matrices(int S, int C, int node_count, const double
 // tipmask: [T][P] 4-bit ambiguity masks
 // lscale: [(N - T)][P] cumulative log scale factors (SCALE only)
 // dynamic LDS: 4 * G*C*64 doubles (two double-buffered exchanges) + G doubles (reduction)
-template <bool SCALE, bool ROOT>
-__global__ __launch_bounds__(MAX_WAVES *WAVE) void k_lower4(const NodeOp *__restrict__ ops, int T, int P, int C,
+template <int WAVES, bool SCALE, bool ROOT>
+__global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict__ ops, int T, int P, int C,
                                                             const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
                                                             const double *__restrict__ mats, double *__restrict__ lscale,
                                                             const double *__restrict__ freqs, const double *__restrict__ props,
                                                             const double *__restrict__ weights, double *__restrict__ pattern_lk,
-                                                            double *__restrict__ lnl_part) {
+                                                            double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
 	extern __shared__ double sh[];
 	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const NodeOp op = ops[blockIdx.y];
 	const size_t plane = (size_t)P * 4;  // one category of one node
 	const bool ltip = op.left < T, rtip = op.right < T;
-	const double *Ml = mats + ((size_t)op.left * C + c) * 16;
-	const double *Mr = mats + ((size_t)op.right * C + c) * 16;
+	const cptr Ml = as_const(mats + ((size_t)op.left * C + c) * 16);
+	const cptr Mr = as_const(mats + ((size_t)op.right * C + c) * 16);
 	const double *pl = ltip ? nullptr : lower + ((size_t)(op.left - T) * C + c) * plane;
 	const double *pr = rtip ? nullptr : lower + ((size_t)(op.right - T) * C + c) * plane;
 	double *dst = lower + ((size_t)(op.parent - T) * C + c) * plane;
@@ -210,8 +215,10 @@ __global__ __launch_bounds__(MAX_WAVES *WAVE) void k_lower4(const NodeOp *__rest
 				for (int cc = 0; cc < C; cc++) L += yb[(g * C + cc) * WAVE + lane];
 				const double lk = log(L) + sf;
 				if (valid) {
+					const double w = weights[k];
 					pattern_lk[k] = lk;
-					acc += lk * weights[k];
+					if (!SCALE) w_over_L[k] = w / L;  // the gradient's w_k / L_k (treelikelihood.c:2879), formed once per pattern
+					acc += lk * w;
 				}
 			}
 		}
@@ -238,25 +245,27 @@ __global__ __launch_bounds__(MAX_WAVES *WAVE) void k_lower4(const NodeOp *__rest
 //   u_l = a o br,   u_r = a o bl                                       (treelikelihood.c:2142-2147)
 //   den_c  = sum_i f_i a_i bl_i br_i      = L_kc in this branch's (scaled) units
 //   num_lc = sum_i f_i u_l,i (Q bl)_i     since (dP/dt) p = Q P p     (treelikelihood.c:2846-2939), f = 1 if FOLD else pi
-//   g[l][c] += w_k num_lc / sum_c' w_c' den_c'       (COMPAT: / den_c, treelikelihood.c:2851-2870)
+//   g[l][c] += w_k num_lc / L_k.  Unscaled: w_k / L_k comes from the root kernel.  Rescaled: L_k in this branch's
+//   units = sum_c' w_c' den_c' (COMPAT: den_c alone, treelikelihood.c:2851-2870)
 // upper: slot s at upper + s * C*P*4.  gpart: [(N*C)][nblk] per-block partial sums.
 // dynamic LDS: 6 * G*C*64 doubles (three double-buffered exchanges) + 2*G*C doubles (reduction)
-template <bool SCALE, bool FOLD, bool COMPAT>
-__global__ __launch_bounds__(MAX_WAVES *WAVE) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
+template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
+__global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
                                                             const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
                                                             double *__restrict__ upper, const double *__restrict__ mats,
                                                             const double *__restrict__ Q, const double *__restrict__ freqs,
                                                             const double *__restrict__ props, const double *__restrict__ weights,
-                                                            const double *__restrict__ pattern_lk, double *__restrict__ gpart, int nblk) {
+                                                            const double *__restrict__ w_over_L, double *__restrict__ gpart, int nblk) {
 	extern __shared__ double sh[];
 	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const NodeOp op = ops[blockIdx.y];
 	const size_t plane = (size_t)P * 4;
 	const bool ltip = op.left < T, rtip = op.right < T, proot = op.upper_slot_parent < 0;
-	const double *Mp = mats + ((size_t)op.parent * C + c) * 16;
-	const double *Ml = mats + ((size_t)op.left * C + c) * 16;
-	const double *Mr = mats + ((size_t)op.right * C + c) * 16;
+	const cptr Mp = as_const(mats + ((size_t)op.parent * C + c) * 16);
+	const cptr Ml = as_const(mats + ((size_t)op.left * C + c) * 16);
+	const cptr Mr = as_const(mats + ((size_t)op.right * C + c) * 16);
+	const cptr Qc = as_const(Q);
 	const double *pl = ltip ? nullptr : lower + ((size_t)(op.left - T) * C + c) * plane;
 	const double *pr = rtip ? nullptr : lower + ((size_t)(op.right - T) * C + c) * plane;
 	const double *up = proot ? nullptr : upper + ((size_t)op.upper_slot_parent * C + c) * plane;
@@ -280,30 +289,33 @@ __global__ __launch_bounds__(MAX_WAVES *WAVE) void k_upper4(const NodeOp *__rest
 		const d4 br = matvec4(opaque(Mr), vr);
 		d4 ul = mul4(a, br), ur = mul4(a, bl);
 		const double den = dot4(mul4(f, a), mul4(bl, br));
-		const double numl = dot4(mul4(f, ul), matvec4(opaque(Q), bl));
-		const double numr = dot4(mul4(f, ur), matvec4(opaque(Q), br));
-		double *xb = sh + (q & 1) * 3 * xsz;
-		const int xi = (g * C + c) * WAVE + lane;
-		xb[xi] = props[c] * den;
-		if (SCALE) {
+		const double numl = dot4(mul4(f, ul), matvec4(opaque(Qc), bl));
+		const double numr = dot4(mul4(f, ur), matvec4(opaque(Qc), br));
+		if (!SCALE) {
+			// unscaled: divide by the site likelihood formed at the root, like the reference (treelikelihood.c:2879);
+			// no cross-category exchange, no barrier, no division in this kernel
+			const double wl = valid ? w_over_L[k] : 0.0;
+			gl += wl * numl;
+			gr += wl * numr;
+		} else {
+			// rescaled: L_k underflows by construction, so the mixture likelihood is re-formed in this branch's scaled
+			// units from all categories' den (exchange through LDS); the scale factors cancel in num / D
+			double *xb = sh + (q & 1) * 3 * xsz;
+			const int xi = (g * C + c) * WAVE + lane;
+			xb[xi] = props[c] * den;
 			xb[xsz + xi] = max4(ul);
 			xb[2 * xsz + xi] = max4(ur);
-		}
-		__syncthreads();
-		double D = 0.0;
-		for (int cc = 0; cc < C; cc++) D += xb[(g * C + cc) * WAVE + lane];
-		const double w = valid ? weights[k] : 0.0;
-		// FOLD without rescaling is the reference's include_root_freqs = true arithmetic: it divides by exp(lnL_k)
-		// (treelikelihood.c:3207-3210), which for non-uniform pi is NOT the branch-local mixture sum D.
-		const double d = (SCALE && COMPAT) ? den : ((FOLD && !SCALE) ? exp(pattern_lk[k]) : D);
-		gl += w * numl / d;
-		gr += w * numr / d;
-		if (SCALE) {  // uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796); the factors cancel in num/den
-			double ml = 0.0, mr = 0.0;
+			__syncthreads();
+			double D = 0.0, ml = 0.0, mr = 0.0;
 			for (int cc = 0; cc < C; cc++) {
+				D += xb[(g * C + cc) * WAVE + lane];
 				ml = fmax(ml, xb[xsz + (g * C + cc) * WAVE + lane]);
 				mr = fmax(mr, xb[2 * xsz + (g * C + cc) * WAVE + lane]);
 			}
+			const double wi = (valid ? weights[k] : 0.0) / (COMPAT ? den : D);
+			gl += wi * numl;
+			gr += wi * numr;
+			// uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
 			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
 			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
 		}
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(MAX_WAVES *WAVE) void k_upper4(const NodeOp *__rest
 		if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
 	}
 	// fixed-order reduction: lanes (shuffle) -> pattern groups (LDS) -> one slab entry per (child, category)
-	double *red = sh + 6 * xsz;
+	double *red = sh + (SCALE ? 6 * xsz : 0);  // the exchange buffers exist only in the rescaled variant
 	const double sl = wave_sum(gl), sr = wave_sum(gr);
 	if (lane == 0) {
 		red[(g * C + c) * 2] = sl;
@@ -386,6 +398,7 @@ struct phyamd_engine {
 	double *d_Q = nullptr;
 	bool have_Q = false;
 	double *d_model = nullptr, *d_freqs = nullptr, *d_rates = nullptr, *d_props = nullptr, *d_lengths = nullptr, *d_weights = nullptr;
+	double *d_wl = nullptr;  // [P] w_k / L_k from the root kernel (unscaled evaluations)
 	double *d_plk = nullptr, *d_lscale = nullptr, *d_lnl_part = nullptr, *d_gpart = nullptr, *d_result = nullptr;
 	uint8_t *d_explicit = nullptr, *d_row_valid = nullptr;
 	NodeOp *d_lower_ops = nullptr, *d_upper_ops = nullptr;
@@ -574,7 +587,7 @@ int update_matrices(phyamd_engine *e) {
 
 dim3 block_dims(const phyamd_engine *e) { return dim3(WAVE, e->C, e->G); }
 
-template <bool SCALE>
+template <int WAVES, bool SCALE>
 int launch_lower_levels(phyamd_engine *e) {
 	const int levels = (int)e->lower_level_off.size() - 1;
 	const size_t lds = sizeof(double) * ((size_t)4 * e->G * e->C * WAVE + e->G);
@@ -584,42 +597,59 @@ int launch_lower_levels(phyamd_engine *e) {
 		const bool is_root = lv == levels - 1;
 		dim3 grid(e->nblk, cnt);
 		if (is_root)
-			hipLaunchKernelGGL((k_lower4<SCALE, true>), grid, block_dims(e), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->C, e->d_tipmask,
-			                   e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_lnl_part);
+			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, true>), grid, block_dims(e), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
+			                   e->d_lnl_part);
 		else
-			hipLaunchKernelGGL((k_lower4<SCALE, false>), grid, block_dims(e), SCALE ? lds : 0, e->stream, e->d_lower_ops + off, e->T, e->P, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_lnl_part);
+			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, false>), grid, block_dims(e), SCALE ? lds : 0, e->stream, e->d_lower_ops + off, e->T, e->P,
+			                   e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
+			                   e->d_lnl_part);
 	}
 	HIP_TRY(hipGetLastError());
 	e->prof.lower_launches = levels;
 	return PHYAMD_OK;
 }
 
-int launch_lower(phyamd_engine *e) { return e->scaling_on ? launch_lower_levels<true>(e) : launch_lower_levels<false>(e); }
+template <int WAVES>
+int launch_lower_w(phyamd_engine *e) {
+	return e->scaling_on ? launch_lower_levels<WAVES, true>(e) : launch_lower_levels<WAVES, false>(e);
+}
 
-template <bool SCALE, bool FOLD, bool COMPAT>
+template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
 int launch_upper_levels(phyamd_engine *e) {
 	const int levels = (int)e->upper_level_off.size() - 1;
-	const size_t lds = sizeof(double) * ((size_t)6 * e->G * e->C * WAVE + 2 * e->G * e->C);
+	const size_t lds = sizeof(double) * ((SCALE ? (size_t)6 * e->G * e->C * WAVE : 0) + 2 * e->G * e->C);
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		dim3 grid(e->nblk, cnt);
-		hipLaunchKernelGGL((k_upper4<SCALE, FOLD, COMPAT>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C, e->d_tipmask,
-		                   e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_gpart, e->nblk);
+		hipLaunchKernelGGL((k_upper4<WAVES, SCALE, FOLD, COMPAT>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C,
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_wl, e->d_gpart,
+		                   e->nblk);
 	}
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = levels;
 	return PHYAMD_OK;
 }
 
-int launch_upper(phyamd_engine *e, int flags) {
+template <int WAVES>
+int launch_upper_w(phyamd_engine *e, int flags) {
 	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS, compat = (flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on;
 	if (e->scaling_on) {
-		if (fold) return compat ? launch_upper_levels<true, true, true>(e) : launch_upper_levels<true, true, false>(e);
-		return compat ? launch_upper_levels<true, false, true>(e) : launch_upper_levels<true, false, false>(e);
+		if (fold) return compat ? launch_upper_levels<WAVES, true, true, true>(e) : launch_upper_levels<WAVES, true, true, false>(e);
+		return compat ? launch_upper_levels<WAVES, true, false, true>(e) : launch_upper_levels<WAVES, true, false, false>(e);
 	}
-	return fold ? launch_upper_levels<false, true, false>(e) : launch_upper_levels<false, false, false>(e);
+	return fold ? launch_upper_levels<WAVES, false, true, false>(e) : launch_upper_levels<WAVES, false, false, false>(e);
+}
+
+// workgroups hold C*G waves; the bound is a template parameter so small groups are not register-capped for 1024 threads
+int launch_lower(phyamd_engine *e) {
+	const int waves = e->C * e->G;
+	return waves <= 4 ? launch_lower_w<4>(e) : waves <= 8 ? launch_lower_w<8>(e) : launch_lower_w<16>(e);
+}
+int launch_upper(phyamd_engine *e, int flags) {
+	const int waves = e->C * e->G;
+	return waves <= 4 ? launch_upper_w<4>(e, flags) : waves <= 8 ? launch_upper_w<8>(e, flags) : launch_upper_w<16>(e, flags);
 }
 
 void record(phyamd_engine *e, int i) {
@@ -766,6 +796,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if ((rc = dev_alloc(e, &e->d_lengths, (size_t)e->N))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_weights, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_plk, (size_t)e->P))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_wl, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)e->nblk))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_gpart, (size_t)e->N * e->C * e->nblk))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_result, (size_t)1 + e->N * e->C))) return bail(rc);
@@ -792,7 +823,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
 	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q,
-	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk,
+	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})
 		if (p) (void)hipFree(p);
