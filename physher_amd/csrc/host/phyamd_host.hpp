@@ -1,0 +1,121 @@
+// phyamd_host.hpp -- host-side model code for the tree-likelihood hot path (C++17, no GPU code here).
+//
+// What stays on the host in physher stays on the host here: Newick parsing and the
+// node-id convention, sequence encoding and site-pattern compression, substitution-model eigen systems,
+// discrete-rate site models, the node-height (ratio) transform and the O(N) gradient epilogue.  Everything
+// O(patterns x nodes) goes through the C ABI in include/physher_amd.h.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace phyamd {
+
+struct Error : std::runtime_error {
+	using std::runtime_error::runtime_error;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Tree (reference: src/phyc/tree.c, node.c, treetransform.c)
+// ---------------------------------------------------------------------------------------------
+struct Tree {
+	int tip_count = 0, node_count = 0, root = -1;
+	// indexed by node id: tips 0..T-1 = index in the taxon list, internals T.. in post-order (tree.c:202-224)
+	std::vector<int> left, right, parent, class_id;
+	std::vector<std::string> name;
+	std::vector<double> distance;  // branch above the node (unrooted mode)
+	std::vector<double> height;    // time mode
+	std::vector<int> postorder, preorder;  // node ids, left before right (tree.c:1772-1790)
+	bool time_mode = false;
+
+	// time trees: ratio/root-height reparameterisation (treetransform.c)
+	std::vector<double> lowers;  // by node id: max tip height below the node
+	std::vector<double> ratios;  // by class_id (internal nodes); the root's entry is its height
+	bool reparameterized = false;
+
+	bool is_leaf(int n) const { return left[n] < 0; }
+	int sibling(int n) const { return left[parent[n]] == n ? right[parent[n]] : left[parent[n]]; }
+};
+
+// Newick -> binary tree with the reference's conventions (tree.c:577-788): polytomies are resolved by inserting
+// zero-length (tip) or BL_MIN (clade) nodes to the right; ids from `taxa`.  contain_bl: lengths are floored at BL_MIN.
+Tree parse_newick(const std::string &newick, const std::vector<std::string> &taxa, bool contain_bl);
+// new_TreeModel_from_newick with dates == NULL (tree.c:1409-1445): unrooted, root->right folded into root->left
+Tree make_unrooted_tree(const std::string &newick, const std::vector<std::string> &taxa);
+// new_TimeTreeModel_from_newick (tree.c:1447-1462): tip heights from dates (init_dates2, tree.c:394-424),
+// internal heights from distances (tree.c:498-515)
+Tree make_time_tree(const std::string &newick, const std::vector<std::string> &taxa, const std::vector<double> &dates);
+// TreeModel_set_transform(RATIO): lowers + ratios from the current heights (treetransform.c:248-262, tree.c:516-535)
+void enable_ratio_transform(Tree &t);
+void heights_from_ratios(Tree &t);  // tree_transform_update_heights (treetransform.c:224-238)
+// d f / d(ratios, root height) given d f / d heights (both by class_id): Tree_node_transform_jvp
+void ratio_transform_jvp(const Tree &t, const double *height_gradient, double *gradient);
+double ratio_transform_log_jacobian(const Tree &t);                     // treetransform.c:214-222
+void ratio_transform_log_jacobian_gradient(const Tree &t, double *gradient);  // += (treetransform.c:183-212)
+
+// ---------------------------------------------------------------------------------------------
+// Sequences and site patterns (reference: datatype.c, sitepattern.c, hashtable.c)
+// ---------------------------------------------------------------------------------------------
+enum class DataTypeKind { Nucleotide, AminoAcid, Codon, General };
+
+struct DataType {
+	DataTypeKind kind = DataTypeKind::Nucleotide;
+	int state_count = 4;
+	int symbol_length = 1;
+	std::vector<std::string> states;  // General
+	int encode(const char *sym) const;                 // datatype.c:55-89, sitepattern.c:796-819
+	void partial(int code, double *out) const;         // ambiguity mask / one-hot / all ones (datatype.h:26-66, datatype.c:212-240)
+};
+
+struct Patterns {
+	int taxon_count = 0, pattern_count = 0, site_count = 0;
+	std::vector<std::string> names;
+	std::vector<uint8_t> states;  // [taxon][pattern]
+	std::vector<double> weights;  // [pattern]
+};
+
+// new_SitePattern (sitepattern.c:186-251): de-duplicate columns, bit-exact in the reference's hashtable order
+Patterns compress_patterns(const DataType &dt, const std::vector<std::string> &names, const std::vector<std::string> &sequences);
+
+// ---------------------------------------------------------------------------------------------
+// Substitution models (reference: substmodel.c, gtr.c, hky.c, jc69.c, gensubst.c, eigen.c)
+// ---------------------------------------------------------------------------------------------
+struct SubstModel {
+	int S = 4;
+	std::string name;
+	std::vector<double> rates;        // model-specific (HKY: kappa; GTR: 5 relative or 6 simplex; General: by structure)
+	std::vector<double> freqs;        // [S]
+	std::vector<unsigned> structure;  // General: upper-triangle -> rate index (gensubst.c)
+	bool normalize = true;
+	// derived
+	std::vector<double> Q, eval, evec, ivec;  // row-major
+	bool dirty = true;
+	void update();                                // build Q (normalised, rows sum to 0) and its eigen system
+	void p_t(double t, double *P, bool derivative = false);  // host reference of M1/M2, used by tests
+};
+void build_symmetric_rates(const SubstModel &m, std::vector<double> &R);  // exchangeabilities r_ij (i < j), row-major full matrix
+
+// ---------------------------------------------------------------------------------------------
+// Site models (reference: sitemodel.c, gamma.c)
+// ---------------------------------------------------------------------------------------------
+enum class RateDistribution { Constant, Gamma, Weibull };
+struct SiteModel {
+	RateDistribution dist = RateDistribution::Constant;
+	int cat_count = 1;  // includes the invariant category
+	double shape = 1.0;
+	bool has_pinv = false;
+	double pinv = 0.0;
+	bool has_mu = false;
+	double mu = 1.0;
+	std::vector<double> cat_rates, cat_props;  // without mu
+	bool dirty = true;
+	void update();
+	double rate(int c) { update(); return cat_rates[c] * (has_mu ? mu : 1.0); }
+};
+double gamma_quantile(double p, double shape, double rate);  // lower-tail inverse CDF (gamma.c:55-58,194-228)
+double reg_lower_gamma(double a, double x);                  // P(a, x)
+
+}  // namespace phyamd

@@ -1,0 +1,138 @@
+"""GPU end-to-end tests through the phycpp-compatible classes (what torchtree-physher would drive):
+alignment + newick + model parameters in, lnL and gradient out, against the reference's golden vectors
+and its own known-answer constants (tests/test_tree_likelihood.c)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, UNROOTED_CASES, load, read_fasta, read_spec
+
+pytestmark = pytest.mark.gpu
+
+CASES4 = [c for c in UNROOTED_CASES if read_spec(c)["datatype"] == "nucleotide" and read_spec(c)["rescale"] == "0"
+          and not load(c)["rescaled"]]
+
+
+def _build(case, pc):
+    gold = load(case)
+    spec = read_spec(case)
+    names, seqs = read_fasta(os.path.join(GOLDEN, case, "aln.fa"))
+    with open(os.path.join(GOLDEN, case, "tree.nwk")) as f:
+        newick = f.read().strip()
+    tree = pc.UnRootedTreeModelInterface(newick, names)
+    f = list(map(float, gold["frequencies"]))
+    if spec["model"] == "jc69":
+        subst = pc.JC69Interface()
+    elif spec["model"] == "hky":
+        subst = pc.HKYInterface(float(spec["rates"]), f)
+    else:
+        subst = pc.GTRInterface([float(x) for x in spec["rates"].split(",")], f)
+    C = int(spec["categories"])
+    site = pc.GammaSiteModelInterface(float(spec["alpha"]), C) if C > 1 else pc.ConstantSiteModelInterface()
+    tlk = pc.TreeLikelihoodInterface(list(zip(names, seqs)), tree, subst, site, None, use_tip_states=spec["tipstates"] == "1")
+    return gold, tree, subst, site, tlk
+
+
+@pytest.mark.parametrize("case", CASES4)
+def test_unrooted_likelihood_and_gradient(case):
+    from physher_amd import _phycpp_amd as pc
+    gold, tree, subst, site, tlk = _build(case, pc)
+    N = gold["node_count"]
+    assert tlk.get_pattern_count() == gold["pattern_count"]
+    assert np.array_equal(tlk.pattern_states(), gold["patterns"]) and np.array_equal(tlk.pattern_weights(), gold["weights"])
+    lnl = tlk.log_likelihood()
+    assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+    assert tlk.gradient_length == N - 2  # physher.cpp:639-641
+    # reference arithmetic (include_root_freqs = true): what physher returns for TREE_MODEL-only requests
+    tlk.set_reference_compatibility(True)
+    g = tlk.gradient()
+    ref = gold["gradient_tree"][: N - 2]
+    assert np.abs(g - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    # default: exact derivative (= the reference's own numbers when it also differentiates the substitution model)
+    tlk.set_reference_compatibility(False)
+    g = tlk.gradient()
+    if gold["gradient_all_flags"] & 4:
+        ref = gold["gradient_all"][: N - 2]
+        assert np.abs(g - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    # ... and it IS the derivative: central differences through SetParameters
+    p = tree.get_parameters()
+    rng = np.random.default_rng(0)
+    for i in rng.choice(N - 2, size=3, replace=False):
+        h = 1e-6
+        pp, pm = p.copy(), p.copy()
+        pp[i] += h
+        pm[i] -= h
+        tree.set_parameters(pp)
+        up = tlk.log_likelihood()
+        tree.set_parameters(pm)
+        dn = tlk.log_likelihood()
+        assert abs((up - dn) / (2 * h) - g[i]) <= 2e-5 * max(1.0, abs(g[i]))
+    tree.set_parameters(p)
+    assert abs(tlk.log_likelihood() - lnl) <= 1e-12 * abs(lnl)
+
+
+def test_parameter_updates_propagate():
+    from physher_amd import _phycpp_amd as pc
+    gold, tree, subst, site, tlk = _build("gtr_g4_t16", pc)
+    l0 = tlk.log_likelihood()
+    site.set_shape(1.7)
+    l1 = tlk.log_likelihood()
+    subst.set_rates(np.array([1.0, 2.0, 1.0, 1.0, 2.0]))
+    l2 = tlk.log_likelihood()
+    subst.set_frequencies(np.array([0.25, 0.25, 0.25, 0.25]))
+    l3 = tlk.log_likelihood()
+    assert len({round(x, 6) for x in (l0, l1, l2, l3)}) == 4
+    site.set_shape(0.5)
+    subst.set_rates(np.array([1.2, 3.1, 0.7, 0.9, 2.8]))
+    subst.set_frequencies(np.array(gold["frequencies"]))
+    assert abs(tlk.log_likelihood() - l0) <= 1e-11 * abs(l0)
+    with pytest.raises(pc.PhyamdError):
+        tlk.request_gradient([pc.TreeLikelihoodGradientFlags.SUBSTITUTION_MODEL])  # loud: not built yet
+
+
+def _fluA(pc, include_jacobian):
+    d = os.path.join(GOLDEN, "fluA_jc69_time")
+    with open(os.path.join(d, "jc69-time.json")) as f:
+        js = json.load(f)
+    tree_js = js["model"]["tree"]
+    names, seqs = read_fasta(os.path.join(d, "fluA.fa"))
+    dates = [float(tree_js["dates"][t]) for t in names]
+    tree = pc.ReparameterizedTimeTreeModelInterface(tree_js["newick"], names, dates, pc.TreeTransformFlags.RATIO)
+    clock = pc.StrictClockModelInterface(0.001, tree)
+    subst = pc.JC69Interface()
+    site = pc.ConstantSiteModelInterface()
+    tlk = pc.TreeLikelihoodInterface(list(zip(names, seqs)), tree, subst, site, clock, use_tip_states=True, include_jacobian=include_jacobian)
+    return tree, clock, tlk
+
+
+def test_fluA_reference_known_answers():
+    """The reference's only known-answer test (tests/test_tree_likelihood.c:29-131), constants copied from it."""
+    from physher_amd import _phycpp_amd as pc
+    gold = load("fluA_jc69_time")
+    tree, clock, tlk = _fluA(pc, include_jacobian=False)
+    assert abs(tlk.log_likelihood() - (-4777.616349713985)) < 1e-8
+    tlk.request_gradient([pc.TreeLikelihoodGradientFlags.TREE_HEIGHT, pc.TreeLikelihoodGradientFlags.BRANCH_MODEL])
+    assert tlk.gradient_length == 69
+    g = tlk.gradient()
+    assert abs(g[68] - 328017.6732813406) < 1e-9 * 328017.67  # clock rate (:38)
+    assert abs(g[67] - 17.492484957839924) < 1e-8            # root height (:77)
+    for i, v in {0: -0.5936536642214764, 1: 6.441289658869611, 13: 96.69564894572747, 43: 152.27137882559083, 66: 6.802521820384058}.items():
+        assert abs(g[i] - v) < 1e-8, (i, g[i], v)                # ratios (:53-75)
+    ref = np.array(gold["gradient_tree_clock_jacobian0"])
+    assert np.abs(g - ref).max() <= 1e-10 * np.abs(ref).max()
+
+    tree, clock, tlk = _fluA(pc, include_jacobian=True)
+    assert abs(tlk.log_likelihood() - (-4786.867701371271)) < 1e-8  # (:88)
+    tlk.request_gradient([pc.TreeLikelihoodGradientFlags.TREE_HEIGHT, pc.TreeLikelihoodGradientFlags.BRANCH_MODEL])
+    g = tlk.gradient()
+    assert abs(g[67] - 19.936860572419484) < 1e-8                   # (:117)
+    assert abs(g[2] - 11.202945298115116) < 1e-8 and abs(g[43] - 188.80951477041825) < 1e-8  # (:93, :107)
+    ref = np.array(gold["gradient_tree_clock_jacobian1"])
+    assert np.abs(g - ref).max() <= 1e-10 * np.abs(ref).max()
+    # cache / update behaviour exercised by the reference test (:37-50): changing the clock and restoring it
+    clock.set_rate(0.002)
+    assert abs(tlk.log_likelihood() - (-4786.867701371271)) > 1.0
+    clock.set_rate(0.001)
+    assert abs(tlk.log_likelihood() - (-4786.867701371271)) < 1e-8
