@@ -530,12 +530,10 @@ void TreeLikelihoodInterface::Gradient(double *gradient) {
 	if (flags_ & (int)TreeLikelihoodGradientFlags::TREE_HEIGHT) {
 		if (!t.time_mode) {
 			const int rl = t.left[t.root], rr = t.right[t.root];
-			if (!t.is_leaf(rr)) g[rr] = 0.0;  // treelikelihood.c:3249-3255
-			else {
-				// bifurcating-root newick with a tip on the right: the merged root branch is parameter nodeMap_[rr] (physher.cpp:59-61);
-				// the reference reports 0 there, this reports its derivative
-				g[rr] = g[rl];
-			}
+			// treelikelihood.c:3249-3255 zeroes root->right.  With a bifurcating-root newick whose right child is a tip, the
+			// merged root branch is parameter nodeMap_[rr] (physher.cpp:59-61), so the reference reports 0 for a live
+			// parameter; outside compatibility mode its derivative (that of root->left) is reported there instead.
+			g[rr] = (t.is_leaf(rr) && !referenceCompat_) ? g[rl] : 0.0;
 			for (int i = 0; i < N - 2; i++) gradient[treeModel_->nodeMap_[i]] = g[i];  // physher.cpp:649-655
 			j = (size_t)N - 2;
 		} else {

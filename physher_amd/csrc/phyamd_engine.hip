@@ -312,9 +312,10 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict
 				ml = fmax(ml, xb[xsz + (g * C + cc) * WAVE + lane]);
 				mr = fmax(mr, xb[2 * xsz + (g * C + cc) * WAVE + lane]);
 			}
-			const double wi = (valid ? weights[k] : 0.0) / (COMPAT ? den : D);
-			gl += wi * numl;
-			gr += wi * numr;
+			// num / L first: with COMPAT both can be denormal (a category that has underflowed) and 1 / den alone overflows
+			const double w = valid ? weights[k] : 0.0, d = COMPAT ? den : D;
+			gl += w * (numl / d);
+			gr += w * (numr / d);
 			// uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
 			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
 			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
