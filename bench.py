@@ -160,12 +160,13 @@ def main():
 
     from physher_amd import synth
     from physher_amd.engine import RESCALE_AUTO, Engine
+    from physher_amd.sharding import ShardedLikelihood, shard_range
 
     T, P, C = args.taxa, args.patterns, args.categories
     rng = np.random.default_rng(args.seed)
     tree = synth.random_tree(T, rng)  # identical on every rank
     # contiguous shard of the pattern list; generated block-wise so the data do not depend on N
-    lo, hi = rank * P // world, (rank + 1) * P // world
+    lo, hi = shard_range(P, rank, world)
     BLK = int(os.environ.get("PHYAMD_BENCH_BLOCK", "125000"))  # profiling runs use one big block: fewer generator kernels
     chunks = []
     for b0 in range(0, P, BLK):
@@ -204,18 +205,12 @@ def main():
 
     N = 2 * T - 1
     result = torch.zeros(1 + N * C, dtype=torch.float64, device=device)
-    host = torch.empty(1 + N * C, dtype=torch.float64, pin_memory=True)
 
-    def step():
+    def evaluate_shard(out):
         eng.set_branch_lengths(tree.length)  # invalidates every P(t): full recompute (benchmarking.c:498-500)
-        eng.gradient_device(result.data_ptr())
-        if world > 1:
-            dist.all_reduce(result)
-        host.copy_(result, non_blocking=False)
-        r = host.numpy()
-        cg = r[1:].reshape(N, C)
-        bg = (cg * (cat_props * cat_rates)[None, :]).sum(axis=1) if C > 1 else cg[:, 0]  # treelikelihood.c:3129-3143
-        return float(r[0]), bg
+        eng.gradient_device(out.data_ptr())  # HIP kernels on torch's current stream; [lnL, g[node][cat]] stays on the device
+
+    step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result)  # + one RCCL all-reduce + host epilogue
 
     def fence():
         torch.cuda.synchronize(device)
