@@ -152,11 +152,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    # PHYAMD_BENCH_REHEARSAL=1: every rank uses cuda:0 and a gloo group -- to rehearse the N > 1 code path on a one-GPU box
+    rehearsal = os.environ.get("PHYAMD_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from physher_amd import synth
     from physher_amd.engine import RESCALE_AUTO, Engine
@@ -210,7 +217,7 @@ def main():
         eng.set_branch_lengths(tree.length)  # invalidates every P(t): full recompute (benchmarking.c:498-500)
         eng.gradient_device(out.data_ptr())  # HIP kernels on torch's current stream; [lnL, g[node][cat]] stays on the device
 
-    step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result)  # + one RCCL all-reduce + host epilogue
+    step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result, via_host=rehearsal)  # + one RCCL all-reduce + host epilogue
 
     def fence():
         torch.cuda.synchronize(device)
@@ -231,7 +238,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     for k in prof:

@@ -18,11 +18,19 @@ def shard_range(pattern_count: int, rank: int, world: int):
     return rank * pattern_count // world, (rank + 1) * pattern_count // world
 
 
-def all_reduce_result(result, world: int):
-    """In-place SUM of the per-shard [lnL, cat-gradient] vector (a torch tensor on the engine's device)."""
+def all_reduce_result(result, world: int, via_host: bool = False):
+    """In-place SUM of the per-shard [lnL, cat-gradient] vector (a torch tensor on the engine's device).
+
+    via_host: rehearsal mode for a one-GPU box (several ranks share the card, gloo group): the 64 KB vector makes a
+    round trip through host memory because gloo cannot reduce device tensors on ROCm."""
     if world > 1:
         import torch.distributed as dist
-        dist.all_reduce(result, op=dist.ReduceOp.SUM)
+        if via_host and result.is_cuda:
+            tmp = result.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            result.copy_(tmp)
+        else:
+            dist.all_reduce(result, op=dist.ReduceOp.SUM)
     return result
 
 
@@ -42,7 +50,8 @@ class ShardedLikelihood:
     Engine.gradient_device(out.data_ptr()) -- the HIP kernels -- and in the CPU tests a stand-in.
     """
 
-    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer):
+    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False):
+        self.via_host = via_host
         self.evaluate_shard = evaluate_shard
         self.N = node_count
         self.cat_rates = np.asarray(cat_rates, dtype=np.float64)
@@ -52,6 +61,6 @@ class ShardedLikelihood:
 
     def __call__(self):
         self.evaluate_shard(self.result)
-        all_reduce_result(self.result, self.world)
+        all_reduce_result(self.result, self.world, self.via_host)
         host = self.result.detach().cpu().numpy()
         return epilogue(host, self.N, self.cat_rates, self.cat_props)
