@@ -359,7 +359,7 @@ __global__ void k_fill_nan(double *out, int n) {
 	if (i < n) out[i] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
-// layout conversion helpers for phyamd_set_tip_partials with S == 4 when values are 0/1 masks are done on the host.
+#include "phyamd_general.inc"
 
 }  // namespace
 
@@ -371,6 +371,10 @@ struct phyamd_engine {
 	phyamd_config cfg{};
 	int T = 0, N = 0, P = 0, S = 0, C = 0, root = -1;
 	int G = 1;  // pattern groups (waves along z) per workgroup
+	bool generic = false;  // S != 4: MFMA kernels, plane layout [C][S][Pp]
+	int Pp = 0;            // padded plane stride (generic)
+	int nblk_root = 0;     // workgroups of k_root_finish (generic)
+	double *d_Lc = nullptr;  // [C][P] per-category site likelihoods at the root (generic)
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
@@ -436,7 +440,7 @@ int bind_device(phyamd_engine *e) {
 	return PHYAMD_OK;
 }
 
-size_t node_partial_doubles(const phyamd_engine *e) { return (size_t)e->C * e->P * e->S; }
+size_t node_partial_doubles(const phyamd_engine *e) { return (size_t)e->C * e->S * (e->generic ? e->Pp : e->P); }
 
 // Build the level schedule and the upper-slot assignment.
 int build_schedule(phyamd_engine *e) {
@@ -643,12 +647,67 @@ int launch_upper_w(phyamd_engine *e, int flags) {
 	return fold ? launch_upper_levels<WAVES, false, true, false>(e) : launch_upper_levels<WAVES, false, false, false>(e);
 }
 
+// ---- S != 4: MFMA kernels -----------------------------------------------------------------------------------
+template <typename K>
+int allow_big_lds(K kernel, size_t bytes) {
+	if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	return PHYAMD_OK;
+}
+
+template <int RT, int KT>
+int launch_lower_gen(phyamd_engine *e) {
+	const int levels = (int)e->lower_level_off.size() - 1;
+	const size_t lds = sizeof(double) * 2 * MatImage<RT, KT>::SIZE;
+	int rc;
+	if ((rc = allow_big_lds(k_lower_gen<RT, KT, true>, lds)) || (rc = allow_big_lds(k_lower_gen<RT, KT, false>, lds))) return rc;
+	for (int lv = 0; lv < levels; lv++) {
+		const int off = e->lower_level_off[lv], cnt = e->lower_level_off[lv + 1] - off;
+		if (cnt == 0) continue;
+		dim3 grid(e->nblk, cnt, e->C);
+		if (lv == levels - 1)
+			hipLaunchKernelGGL((k_lower_gen<RT, KT, true>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc);
+		else
+			hipLaunchKernelGGL((k_lower_gen<RT, KT, false>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc);
+	}
+	hipLaunchKernelGGL(k_root_finish, dim3(e->nblk_root), dim3(256), 0, e->stream, e->P, e->C, e->d_Lc, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
+	HIP_TRY(hipGetLastError());
+	e->prof.lower_launches = levels;
+	return PHYAMD_OK;
+}
+
+template <int RT, int KT>
+int launch_upper_gen(phyamd_engine *e, int flags) {
+	const int levels = (int)e->upper_level_off.size() - 1;
+	const size_t lds = sizeof(double) * (4 * MatImage<RT, KT>::SIZE + 2 * GenGeo<RT>::WAVES);
+	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS;
+	int rc;
+	if ((rc = allow_big_lds(k_upper_gen<RT, KT, true>, lds)) || (rc = allow_big_lds(k_upper_gen<RT, KT, false>, lds))) return rc;
+	for (int lv = 0; lv < levels; lv++) {
+		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
+		if (cnt == 0) continue;
+		dim3 grid(e->nblk, cnt, e->C);
+		if (fold)
+			hipLaunchKernelGGL((k_upper_gen<RT, KT, true>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk);
+		else
+			hipLaunchKernelGGL((k_upper_gen<RT, KT, false>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk);
+	}
+	HIP_TRY(hipGetLastError());
+	e->prof.upper_launches = levels;
+	return PHYAMD_OK;
+}
+
 // workgroups hold C*G waves; the bound is a template parameter so small groups are not register-capped for 1024 threads
 int launch_lower(phyamd_engine *e) {
+	if (e->generic) return e->S == 20 ? launch_lower_gen<2, 5>(e) : e->S == 60 ? launch_lower_gen<4, 15>(e) : launch_lower_gen<4, 16>(e);
 	const int waves = e->C * e->G;
 	return waves <= 4 ? launch_lower_w<4>(e) : waves <= 8 ? launch_lower_w<8>(e) : launch_lower_w<16>(e);
 }
 int launch_upper(phyamd_engine *e, int flags) {
+	if (e->generic) return e->S == 20 ? launch_upper_gen<2, 5>(e, flags) : e->S == 60 ? launch_upper_gen<4, 15>(e, flags) : launch_upper_gen<4, 16>(e, flags);
 	const int waves = e->C * e->G;
 	return waves <= 4 ? launch_upper_w<4>(e, flags) : waves <= 8 ? launch_upper_w<8>(e, flags) : launch_upper_w<16>(e, flags);
 }
@@ -668,9 +727,10 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 	if (e->scaling_on && (rc = ensure_scaling_storage(e))) return rc;
 	for (int attempt = 0; attempt < 2; attempt++) {
 		if ((rc = launch_lower(e))) return rc;
-		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->nblk, (const uint8_t *)nullptr, e->d_result);
+		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->generic ? e->nblk_root : e->nblk, (const uint8_t *)nullptr,
+		                   e->d_result);
 		HIP_TRY(hipGetLastError());
-		if (e->cfg.rescale != PHYAMD_RESCALE_AUTO || e->scaling_on || !need_host_check) break;
+		if (e->cfg.rescale != PHYAMD_RESCALE_AUTO || e->scaling_on || !need_host_check || e->generic) break;
 		// lazy switch (treelikelihood.c:1496-1519): +-inf lnL turns rescaling on for good and recomputes
 		HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double), hipMemcpyDeviceToHost, e->stream));
 		HIP_TRY(hipStreamSynchronize(e->stream));
@@ -735,7 +795,10 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if (cfg->tip_count < 2) return fail(PHYAMD_EINVAL, "tip_count must be >= 2 (got %d)", cfg->tip_count);
 	if (cfg->pattern_count < 1) return fail(PHYAMD_EINVAL, "pattern_count must be >= 1 (got %d)", cfg->pattern_count);
 	if (cfg->category_count < 1) return fail(PHYAMD_EINVAL, "category_count must be >= 1 (got %d)", cfg->category_count);
-	if (cfg->state_count != 4) return fail(PHYAMD_EUNSUPPORTED, "state_count %d: only the 4-state kernels are built in this revision", cfg->state_count);
+	if (cfg->state_count != 4 && cfg->state_count != 20 && cfg->state_count != 60 && cfg->state_count != 61)
+		return fail(PHYAMD_EUNSUPPORTED, "state_count %d: kernels are built for 4, 20, 60 and 61 states", cfg->state_count);
+	if (cfg->state_count != 4 && cfg->rescale == PHYAMD_RESCALE_ALWAYS)
+		return fail(PHYAMD_EUNSUPPORTED, "rescaling is only built for the 4-state kernels in this revision");
 	if (cfg->rescale < 0 || cfg->rescale > 2) return fail(PHYAMD_EINVAL, "rescale must be PHYAMD_RESCALE_*");
 	int ndev = 0;
 	HIP_TRY(hipGetDeviceCount(&ndev));
@@ -774,6 +837,13 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	}
 	e->G = std::max(1, 4 / e->C);  // at least 4 waves per workgroup
 	e->nblk = (e->P + WAVE * e->G * PPT - 1) / (WAVE * e->G * PPT);
+	e->generic = e->S != 4;
+	if (e->generic) {
+		e->Pp = (e->P + 15) / 16 * 16;
+		const int ppb = e->S == 20 ? GenGeo<2>::PATTERNS_PER_BLOCK : GenGeo<4>::PATTERNS_PER_BLOCK;
+		e->nblk = (e->P + ppb - 1) / ppb;
+		e->nblk_root = (e->P + 255) / 256;
+	}
 	e->tip_set.assign(e->T, 0);
 	e->explicit_host.assign(e->N, 0);
 	const size_t np = node_partial_doubles(e);
@@ -798,7 +868,8 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if ((rc = dev_alloc(e, &e->d_weights, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_plk, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_wl, (size_t)e->P))) return bail(rc);
-	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)e->nblk))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)std::max(e->nblk, e->nblk_root)))) return bail(rc);
+	if (e->generic && (rc = dev_alloc(e, &e->d_Lc, (size_t)e->C * e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_gpart, (size_t)e->N * e->C * e->nblk))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_result, (size_t)1 + e->N * e->C))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_explicit, (size_t)e->N))) return bail(rc);
@@ -823,7 +894,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q,
+	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})
@@ -844,7 +915,10 @@ int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states) {
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	std::vector<uint8_t> mask(e->P);
-	for (int k = 0; k < e->P; k++) mask[k] = states[k] < 4 ? (uint8_t)(1u << states[k]) : (uint8_t)0xF;  // code >= S: unknown (treelikelihood4.c:946-988)
+	if (e->generic)
+		for (int k = 0; k < e->P; k++) mask[k] = states[k] < e->S ? states[k] : (uint8_t)e->S;  // raw codes; S = unknown
+	else
+		for (int k = 0; k < e->P; k++) mask[k] = states[k] < 4 ? (uint8_t)(1u << states[k]) : (uint8_t)0xF;  // code >= S: unknown (treelikelihood4.c:946-988)
 	HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->tip_set[tip] = 1;
@@ -857,6 +931,24 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	std::vector<uint8_t> mask(e->P);
+	if (e->generic) {  // one-hot or all-ones vectors only (what datatype.c:212-240 produces without ambiguity tables)
+		const int S = e->S;
+		for (int k = 0; k < e->P; k++) {
+			int ones = 0, last = -1;
+			for (int s = 0; s < S; s++) {
+				const double v = partials[(size_t)k * S + s];
+				if (v == 1.0) ones++, last = s;
+				else if (v != 0.0) return fail(PHYAMD_EUNSUPPORTED, "tip %d pattern %d: only 0/1 tip partials are built", tip, k);
+			}
+			if (ones == 1) mask[k] = (uint8_t)last;
+			else if (ones == S) mask[k] = (uint8_t)S;
+			else return fail(PHYAMD_EUNSUPPORTED, "tip %d pattern %d: partial ambiguity sets are only built for 4 states", tip, k);
+		}
+		HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		e->tip_set[tip] = 1;
+		return PHYAMD_OK;
+	}
 	for (int k = 0; k < e->P; k++) {
 		unsigned m = 0;
 		for (int s = 0; s < 4; s++) {
@@ -1084,22 +1176,35 @@ int phyamd_get_partials(phyamd_engine *e, int node, int upper, double *out) {
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	const size_t np = node_partial_doubles(e);
-	if (!upper) {
-		if (node < e->T) {  // rebuild the replicated tip partial from its mask
-			std::vector<uint8_t> mask(e->P);
-			HIP_TRY(hipMemcpyAsync(mask.data(), e->d_tipmask + (size_t)node * e->P, e->P, hipMemcpyDeviceToHost, e->stream));
-			HIP_TRY(hipStreamSynchronize(e->stream));
-			for (int c = 0; c < e->C; c++)
-				for (int k = 0; k < e->P; k++)
-					for (int s = 0; s < 4; s++) out[((size_t)c * e->P + k) * 4 + s] = (mask[k] >> s) & 1 ? 1.0 : 0.0;
-			return PHYAMD_OK;
-		}
-		HIP_TRY(hipMemcpyAsync(out, e->d_lower + (size_t)(node - e->T) * np, sizeof(double) * np, hipMemcpyDeviceToHost, e->stream));
-	} else {
+	if (upper) {
 		if (!e->keep_partials || !e->upper_valid) return fail(PHYAMD_EINVAL, "upper partials need phyamd_set_keep_partials(1) before phyamd_gradient");
 		if (node == e->root) return fail(PHYAMD_EINVAL, "the root has no upper partial");
-		HIP_TRY(hipMemcpyAsync(out, e->d_upper + (size_t)e->upper_slot[node] * np, sizeof(double) * np, hipMemcpyDeviceToHost, e->stream));
 	}
+	if (!upper && node < e->T) {  // rebuild the replicated tip partial from its mask / code
+		std::vector<uint8_t> mask(e->P);
+		HIP_TRY(hipMemcpyAsync(mask.data(), e->d_tipmask + (size_t)node * e->P, e->P, hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		const int S = e->S;
+		for (int c = 0; c < e->C; c++)
+			for (int k = 0; k < e->P; k++)
+				for (int s = 0; s < S; s++)
+					out[((size_t)c * e->P + k) * S + s] = e->generic ? ((mask[k] >= S || mask[k] == s) ? 1.0 : 0.0) : ((mask[k] >> s) & 1 ? 1.0 : 0.0);
+		return PHYAMD_OK;
+	}
+	const double *src = upper ? e->d_upper + (size_t)e->upper_slot[node] * np : e->d_lower + (size_t)(node - e->T) * np;
+	if (e->generic) {  // planes [C][S][Pp] -> the reference's [C][P][S]
+		double *tmp = nullptr;
+		const size_t cnt = (size_t)e->C * e->P * e->S;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), cnt * sizeof(double)));
+		hipLaunchKernelGGL(k_planes_to_reference, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 4096)), dim3(256), 0, e->stream, e->P, e->Pp, e->S,
+		                   e->C, src, tmp);
+		hipError_t err = hipMemcpyAsync(out, tmp, cnt * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+		if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+		(void)hipFree(tmp);
+		if (err != hipSuccess) return fail(PHYAMD_EDEVICE, "get_partials: %s", hipGetErrorString(err));
+		return PHYAMD_OK;
+	}
+	HIP_TRY(hipMemcpyAsync(out, src, sizeof(double) * np, hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	return PHYAMD_OK;
 }

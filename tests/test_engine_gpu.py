@@ -232,8 +232,11 @@ def test_error_behaviour():
     with pytest.raises(EngineError):
         Engine(4, 10, 4, 17)  # more categories than waves in a workgroup
     with pytest.raises(EngineError) as ei:
-        Engine(4, 10, 20, 4)
+        Engine(4, 10, 7, 4)  # no kernels for 7 states
     assert ei.value.code == -4  # loud, not a silent CPU fallback
+    with pytest.raises(EngineError) as ei:
+        Engine(4, 10, 20, 4, rescale=RESCALE_ALWAYS)  # rescaling is 4-state only for now
+    assert ei.value.code == -4
 
 
 def test_explicit_matrices_jc69():
@@ -264,3 +267,86 @@ def test_explicit_matrices_jc69():
         lnl, cg = e.gradient()
     assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
     assert np.abs(cg - cg_eig).max() <= 1e-9 * max(1.0, np.abs(cg_eig).max())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 20 / 60 / 61 states: the fp64-MFMA kernels (K9)
+# ------------------------------------------------------------------------------------------------------------
+CASES_GEN = [c for c in UNROOTED_CASES if read_spec(c)["datatype"] in ("aa", "codon")]
+
+
+@pytest.mark.parametrize("case", CASES_GEN)
+def test_golden_generic_states(case):
+    """WAG / LG (20 states) and MG94 (61 states) against the compiled reference."""
+    gold = load(case)
+    N = gold["node_count"]
+    pb = oracle_problem(case, gold)
+    with engine_from_problem(pb, rescale=RESCALE_AUTO, tip_mode=_tip_mode(case)) as e:
+        e.set_keep_partials(True)
+        lnl = e.log_likelihood()
+        assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+        # codon P(t) entries for multi-nucleotide changes are ~1e-10 and come out of sums that cancel to 1e-17 absolute:
+        # their RELATIVE accuracy is ~1e-7 in the reference and here alike, and carries into the small partial entries
+        codon = gold["state_count"] > 20
+        np.testing.assert_allclose(e.pattern_log_likelihoods(), gold["pattern_lk"], rtol=1e-9 if codon else 1e-11, atol=1e-11)
+        prtol = 1e-6 if codon else 1e-9
+        np.testing.assert_allclose(e.partials(gold["root"]), gold["partials_root"], rtol=prtol, atol=1e-300)
+        np.testing.assert_allclose(e.partials(gold["tip_count"]), gold["partials_first_internal"], rtol=prtol, atol=1e-300)
+        for q, node in enumerate(gold["pt_nodes"]):
+            np.testing.assert_allclose(e.node_matrices(node), gold["pt"][q], rtol=1e-11, atol=1e-15)
+        # the reference differentiates these models with include_root_freqs = true only (no dPdp): FOLD reproduces it
+        lnl2, cg = e.gradient(GRAD_FOLD_ROOT_FREQS)
+        assert lnl2 == lnl
+        g = po.branch_gradient_from_cat(cg, gold["cat_rates"], gold["cat_proportions"], zero_node=gold["right"][gold["root"]])
+        ref = gold["gradient_tree"]
+        # the reference's 61-state eigen system (orthes + hqr2) satisfies U U^-1 = I only to ~1e-9, so U L e^{Lt} U^-1 p
+        # (reference) and Q (P p) with Q = U L U^-1 (here) agree to ~2e-9 relative instead of 1e-9
+        assert np.abs(g - ref).max() <= _grad_tol(ref) * (10 if codon else 1)
+        np.testing.assert_allclose(e.partials(gold["tip_count"], upper=True), gold["upper_first_internal"], rtol=prtol, atol=1e-300)
+
+
+@pytest.mark.parametrize("S,T,P,C", [(20, 9, 1, 1), (20, 17, 130, 4), (20, 30, 515, 2), (61, 7, 33, 1), (61, 12, 200, 2), (60, 8, 70, 3)])
+def test_generic_states_against_oracle(S, T, P, C):
+    """ragged tile counts (P not a multiple of 16 or of the workgroup's patterns), gaps, every built state count;
+    default gradient (pi applied in the final state sum) including all lower and upper partials"""
+    pb = random_problem(T, P, C, seed=300 + S + T, S=S, gaps=0.05)
+    _compare_with_oracle(pb, RESCALE_NEVER, check_partials=True)
+    pb = random_problem(T, P, C, seed=300 + S + T, S=S, gaps=0.05, fold_root_freqs=1)
+    _compare_with_oracle(pb, RESCALE_NEVER, flags=GRAD_FOLD_ROOT_FREQS)
+
+
+@pytest.mark.parametrize("S,T,P,C", [(20, 200, 50_000, 4), (61, 100, 20_000, 1)])
+def test_generic_full_size_properties(S, T, P, C):
+    """BASELINE configs[2] (WAG-like 20 states) and configs[3] (codon, 61 states) shapes: determinism, weight
+    linearity, sum over patterns, gradient vs central differences."""
+    from physher_amd import synth
+    rng = np.random.default_rng(S)
+    tree = synth.random_tree(T, rng)
+    states = synth.evolve(tree, P, S, rng)
+    weights = rng.integers(1, 4, size=P).astype(np.float64)
+    model = random_problem(4, 8, C, seed=S, S=S)
+    with Engine(T, P, S, C, rescale=RESCALE_AUTO) as e:
+        e.set_topology(tree.left, tree.right, tree.root)
+        e.set_branch_lengths(tree.length)
+        e.set_eigen(model.eval, model.evec, model.ivec)
+        e.set_frequencies(model.freqs)
+        e.set_category_rates(model.cat_rates, model.cat_props)
+        e.set_pattern_weights(weights)
+        for t in range(T):
+            e.set_tip_states(t, states[t])
+        lnl, cg = e.gradient()
+        lnl2, cg2 = e.gradient()
+        assert np.isfinite(lnl) and lnl == lnl2 and np.array_equal(cg, cg2)
+        assert abs(np.dot(e.pattern_log_likelihoods(), weights) - lnl) <= 1e-11 * abs(lnl)
+        e.set_pattern_weights(2.0 * weights)
+        lnl3, cg3 = e.gradient()
+        assert abs(lnl3 - 2 * lnl) <= 1e-12 * abs(lnl) and np.abs(cg3 - 2 * cg).max() <= 1e-11 * np.abs(cg).max()
+        e.set_pattern_weights(weights)
+        bg = po.branch_gradient_from_cat(cg, model.cat_rates, model.cat_props)
+        for n in rng.choice([i for i in range(2 * T - 1) if i != tree.root], size=2, replace=False):
+            h = 1e-6
+            bl = tree.length.copy(); bl[n] += h
+            e.set_branch_lengths(bl); up = e.log_likelihood()
+            bl[n] -= 2 * h
+            e.set_branch_lengths(bl); dn = e.log_likelihood()
+            assert abs((up - dn) / (2 * h) - bg[n]) <= 1e-4 * max(1.0, abs(bg[n]))
