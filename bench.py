@@ -51,24 +51,55 @@ def gtr_eigen():
     return w, V / d[:, None], V.T * d[None, :]
 
 
-def evolve_on_device(tree, site_count, seed, device):
-    """Sequences for every tip, evolved down the tree on the GPU (JC-style, 4 states).  uint8 [T][sites] torch tensor."""
+def evolve_on_device(tree, site_count, seed, device, S=4):
+    """Sequences for every tip, evolved down the tree on the GPU (equal-rates model, S states).  uint8 [T][sites] torch tensor."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     N = tree.node_count
     seqs = [None] * N
-    seqs[tree.root] = torch.randint(0, 4, (site_count,), dtype=torch.uint8, device=device, generator=g)
+    seqs[tree.root] = torch.randint(0, S, (site_count,), dtype=torch.uint8, device=device, generator=g)
     for n in range(N - 1, -1, -1):
         if tree.left[n] < 0:
             continue
         for c in (int(tree.left[n]), int(tree.right[n])):
-            p_same = 0.25 + 0.75 * np.exp(-4.0 / 3.0 * tree.length[c])
+            p_same = 1.0 / S + (1.0 - 1.0 / S) * np.exp(-S / (S - 1.0) * tree.length[c])
             change = torch.rand(site_count, device=device, generator=g) >= p_same
-            new = torch.randint(0, 4, (site_count,), dtype=torch.uint8, device=device, generator=g)
+            new = torch.randint(0, S, (site_count,), dtype=torch.uint8, device=device, generator=g)
             seqs[c] = torch.where(change, new, seqs[n])
         seqs[n] = None
     return torch.stack(seqs[: tree.tip_count])
+
+
+def reversible_eigen(S, seed):
+    """Eigen system of a seeded random reversible S-state model (stand-in for WAG / MG94: same shapes, same work)."""
+    rng = np.random.default_rng(seed)
+    pi = rng.dirichlet(np.full(S, 20.0))
+    r = rng.uniform(0.2, 3.0, size=(S, S))
+    r = 0.5 * (r + r.T)
+    Q = r * pi[None, :]
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(axis=1))
+    Q /= -(pi * np.diag(Q)).sum()
+    d = np.sqrt(pi)
+    B = (d[:, None] * Q) / d[None, :]
+    w, V = np.linalg.eigh(0.5 * (B + B.T))
+    return pi, w, V / d[:, None], V.T * d[None, :]
+
+
+def algorithmic_flops(T, P, C, S):
+    """lower / upper node 2S(2S-1)+S flops per (pattern, category), branch gradient S(2S-1)+2S."""
+    return P * C * ((3 * T - 3) * (2 * S * (2 * S - 1) + S) + (2 * T - 2) * (S * (2 * S - 1) + 2 * S))
+
+
+# BASELINE.json configs[1..4]; the headline metric is quoted on configs[4]'s shape, which fits one GPU (160 GB)
+WORKLOADS = {
+    "cfg2": dict(taxa=500, patterns=100_000, states=4, categories=4, name="GTR+G4 DNA"),
+    "cfg3": dict(taxa=200, patterns=50_000, states=20, categories=4, name="20-state reversible model (WAG+G4 shape)"),
+    "cfg4": dict(taxa=100, patterns=20_000, states=61, categories=1, name="61-state reversible model (MG94 codon shape)"),
+    "cfg5": dict(taxa=1000, patterns=1_000_000, states=4, categories=4, name="GTR+G4 DNA"),
+}
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X spec sheet (fp64 matrix = fp64 vector on CDNA4)
 
 
 def algorithmic_bytes(T, P, C, S):
@@ -131,9 +162,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--taxa", type=int, default=1000)
-    ap.add_argument("--patterns", type=int, default=1_000_000)
-    ap.add_argument("--categories", type=int, default=4)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg5", help="BASELINE.json configs[1..4]; default = the metric's shape")
+    ap.add_argument("--taxa", type=int, default=None)
+    ap.add_argument("--patterns", type=int, default=None)
+    ap.add_argument("--categories", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample-patterns", type=int, default=2000)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -169,7 +201,11 @@ def main():
     from physher_amd.engine import RESCALE_AUTO, Engine
     from physher_amd.sharding import ShardedLikelihood, shard_range
 
-    T, P, C = args.taxa, args.patterns, args.categories
+    wl = WORKLOADS[args.config]
+    T = args.taxa or wl["taxa"]
+    P = args.patterns or wl["patterns"]
+    C = args.categories or wl["categories"]
+    S = wl["states"]
     rng = np.random.default_rng(args.seed)
     tree = synth.random_tree(T, rng)  # identical on every rank
     # contiguous shard of the pattern list; generated block-wise so the data do not depend on N
@@ -180,7 +216,7 @@ def main():
         b1 = min(P, b0 + BLK)
         if b1 <= lo or b0 >= hi:
             continue
-        blk = evolve_on_device(tree, b1 - b0, args.seed * 100003 + b0, device)
+        blk = evolve_on_device(tree, b1 - b0, args.seed * 100003 + b0, device, S)
         chunks.append(blk[:, max(lo, b0) - b0: min(hi, b1) - b0].cpu().numpy())
     states = np.ascontiguousarray(np.concatenate(chunks, axis=1))
     del chunks
@@ -196,14 +232,18 @@ def main():
         cat_rates = np.linspace(0.2, 1.8, C) if C > 1 else np.ones(1)
         cat_rates = cat_rates / cat_rates.mean()
     cat_props = np.full(C, 1.0 / C)
-    ev, U, Ui = gtr_eigen()
+    if S == 4:
+        freqs = np.array(GTR_FREQS)
+        ev, U, Ui = gtr_eigen()
+    else:
+        freqs, ev, U, Ui = reversible_eigen(S, args.seed)
 
     stream = torch.cuda.current_stream(device)
-    eng = Engine(T, Pl, 4, C, device=local_rank, rescale=RESCALE_AUTO, stream=stream.cuda_stream)
+    eng = Engine(T, Pl, S, C, device=local_rank, rescale=RESCALE_AUTO, stream=stream.cuda_stream)
     eng.set_topology(tree.left, tree.right, tree.root)
     eng.set_branch_lengths(tree.length)
     eng.set_eigen(ev, U, Ui)
-    eng.set_frequencies(GTR_FREQS)
+    eng.set_frequencies(freqs)
     eng.set_category_rates(cat_rates, cat_props)
     eng.set_pattern_weights(weights)
     for t in range(T):
@@ -248,7 +288,8 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps / elapsed
-        lower_b, upper_b = algorithmic_bytes(T, Pl, C, 4)  # this rank's shard
+        lower_b, upper_b = algorithmic_bytes(T, Pl, C, S)  # this rank's shard
+        kern = "4" if S == 4 else "_gen"
         launches = max(1, p["upper_launches"])
         achieved = upper_b / (prof["upper_ms"] * 1e-3) / 1e9 if prof["upper_ms"] > 0 else None
         traffic = None
@@ -256,7 +297,7 @@ def main():
             try:
                 with open(args.traffic_json) as f:
                     tj = json.load(f)
-                if tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C:
+                if S == 4 and tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C:
                     traffic = tj["upper_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -273,21 +314,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"GTR+G{C} DNA, {T} taxa x {P} patterns x 4 states x {C} categories, unrooted, full recompute per eval "
-                                   f"(BASELINE configs[4] shape; {Pl} patterns on this rank)",
-                       "taxa": T, "patterns": P, "categories": C, "states": 4, "patterns_per_gpu": Pl, "lnL": lnl,
+            "config": {"workload": f"{wl['name']}, {T} taxa x {P} patterns x {S} states x {C} categories, unrooted, full recompute per eval "
+                                   f"(BASELINE configs[{int(args.config[3]) - 1}] shape; {Pl} patterns on this rank)",
+                       "taxa": T, "patterns": P, "categories": C, "states": S, "patterns_per_gpu": Pl, "lnL": lnl,
                        "rescaling": eng.rescaling, "device_bytes": p["device_bytes"]},
-            "roofline": {"bound": "hbm", "kernel": "k_upper4 (pre-order pass + fused branch gradient)",
+            "roofline": {"bound": "hbm", "kernel": f"k_upper{kern} (pre-order pass + fused branch gradient)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "algorithmic_bytes_per_launch": upper_b / launches, "launches_per_eval": launches,
                          "avg_launch_ms": prof["upper_ms"] / launches,
-                         "lower_kernel": {"kernel": "k_lower4", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
+                         "lower_kernel": {"kernel": f"k_lower{kern}", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
                                           "launches_per_eval": p["lower_launches"], "ms_per_eval": prof["lower_ms"]},
                          "ms_per_eval": {k: prof[k] for k in prof}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if S != 4:  # the 20-/61-state contraction runs on the fp64 matrix cores: report that side of the roofline too
+            fl = algorithmic_flops(T, Pl, C, S)
+            tf = fl / ((prof["lower_ms"] + prof["upper_ms"]) * 1e-3) / 1e12 if prof["upper_ms"] > 0 else None
+            out["roofline"]["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": None if tf is None else tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": fl}
+            if S > 20:
+                out["roofline"]["bound"] = "mfma"
+        if world == 1 and not args.no_cpu_baseline and S == 4:
             cb = cpu_baseline(tree, states, weights, cat_rates, args.cpu_sample_patterns, args.cpu_budget_s)
             scaled = cb["t_eval"] * (P / cb["patterns"])
             out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "evals/s", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
