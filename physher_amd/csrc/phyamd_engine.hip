@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,11 +58,17 @@ constexpr int PPT = 4;               // pattern groups swept by one workgroup (s
 constexpr int MAX_WAVES = 16;        // 1024 threads
 constexpr double SCALING_THRESHOLD = 1.0e-40;  // treelikelihood.c:1121
 
+enum { CH_TIP = 0, CH_CORE = 1, CH_CHERRY = 2, CH_CHERRY_TIP = 3 };  // how a child's lower partial is obtained
+
 struct NodeOp {
 	int32_t parent;  // lower pass: destination node; upper pass: the node whose children are produced
 	int32_t left, right;
 	int32_t upper_slot_parent;  // upper pass: slot of the parent's upper (-1: parent is the root)
-	int32_t upper_slot_left, upper_slot_right;  // slots to write (-1: child is a tip, nothing stored)
+	int32_t upper_slot_left, upper_slot_right;  // slots to write (-1: nothing stored)
+	int32_t core_parent, core_left, core_right;  // index of the stored lower array (-1: tip or fused fringe node)
+	int32_t kind_left, kind_right;               // CH_*
+	int32_t lt0, lt1, lt2, linner;               // left fringe: cherry tips, outer tip, inner cherry node
+	int32_t rt0, rt1, rt2, rinner;               // right fringe
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -156,29 +163,49 @@ __global__ void k_transition_matrices(int S, int C, int node_count, const double
 // 4-state kernels.  Workgroup = (64 lanes = patterns) x (C waves = categories) x (G pattern groups);
 // a wave's category is uniform, so its 4x4 matrices live in SGPRs and feed v_fma_f64 directly.
 // Cross-category quantities (rescaling max, mixture sums) go through a small LDS exchange.
+//
+// Fringe fusion: an internal node whose subtree is a cherry (tip, tip) or a cherry plus a tip is never written to
+// HBM.  Wherever its partial is needed it is recomputed from 2-3 tip bytes in registers, and in the pre-order pass
+// its upper partial is pushed down through it in registers, yielding the gradients of its 2-4 inner branches in the
+// same kernel.  Half of the internal nodes of a random tree are of these two shapes, so both passes move about half
+// the bytes.  (Unfused schedules -- rescaling, keep_partials -- run the same kernels with only tip / stored children.)
 // ------------------------------------------------------------------------------------------------
-// lower: internal-node partials, node n at lower + (n - T) * C*P*4, layout [C][P][4] (the reference's)
+// lower: stored partials, array `core` at lower + core * C*P*4, layout [C][P][4] (the reference's)
 // tipmask: [T][P] 4-bit ambiguity masks
-// lscale: [(N - T)][P] cumulative log scale factors (SCALE only)
+// lscale: [cores][P] cumulative log scale factors (SCALE only)
+
+struct Ctx4 {
+	const uint8_t *__restrict__ tipmask;
+	const double *__restrict__ mats;
+	int P, C, c, k;
+	__device__ __forceinline__ d4 tip(int t) const { return mask4(tipmask[(size_t)t * P + k]); }
+	__device__ __forceinline__ cptr M(int node) const { return opaque(as_const(mats + ((size_t)node * C + c) * 16)); }
+};
+
+// lower partial of one child at (pattern k, category c): tip mask, stored array, or a fringe subtree recomputed in registers
+__device__ __forceinline__ d4 child_value(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
+                                          const double *__restrict__ lower, size_t plane) {
+	if (kind == CH_TIP) return x.tip(node);
+	if (kind == CH_CORE) return load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4);
+	const d4 cherry = mul4(matvec4(x.M(t0), x.tip(t0)), matvec4(x.M(t1), x.tip(t1)));
+	if (kind == CH_CHERRY) return cherry;
+	return mul4(matvec4(x.M(inner), cherry), matvec4(x.M(t2), x.tip(t2)));  // CH_CHERRY_TIP
+}
+
 // dynamic LDS: 4 * G*C*64 doubles (two double-buffered exchanges) + G doubles (reduction)
 template <int WAVES, bool SCALE, bool ROOT>
 __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict__ ops, int T, int P, int C,
-                                                            const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
-                                                            const double *__restrict__ mats, double *__restrict__ lscale,
-                                                            const double *__restrict__ freqs, const double *__restrict__ props,
-                                                            const double *__restrict__ weights, double *__restrict__ pattern_lk,
-                                                            double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
+                                                        const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
+                                                        const double *__restrict__ mats, double *__restrict__ lscale,
+                                                        const double *__restrict__ freqs, const double *__restrict__ props,
+                                                        const double *__restrict__ weights, double *__restrict__ pattern_lk,
+                                                        double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
 	extern __shared__ double sh[];
 	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const NodeOp op = ops[blockIdx.y];
 	const size_t plane = (size_t)P * 4;  // one category of one node
-	const bool ltip = op.left < T, rtip = op.right < T;
-	const cptr Ml = as_const(mats + ((size_t)op.left * C + c) * 16);
-	const cptr Mr = as_const(mats + ((size_t)op.right * C + c) * 16);
-	const double *pl = ltip ? nullptr : lower + ((size_t)(op.left - T) * C + c) * plane;
-	const double *pr = rtip ? nullptr : lower + ((size_t)(op.right - T) * C + c) * plane;
-	double *dst = lower + ((size_t)(op.parent - T) * C + c) * plane;
+	double *dst = lower + ((size_t)op.core_parent * C + c) * plane;
 	const int xsz = G * C * WAVE;  // one exchange buffer
 	double acc = 0.0;
 
@@ -186,10 +213,11 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict
 	for (int q = 0; q < PPT; q++) {
 		const int k0 = ((blockIdx.x * PPT + q) * G + g) * WAVE + lane;
 		const bool valid = k0 < P;
-		const int k = valid ? k0 : P - 1;
-		const d4 a = ltip ? mask4(tipmask[(size_t)op.left * P + k]) : load4(pl + (size_t)k * 4);
-		const d4 b = rtip ? mask4(tipmask[(size_t)op.right * P + k]) : load4(pr + (size_t)k * 4);
-		d4 out = mul4(matvec4(opaque(Ml), a), matvec4(opaque(Mr), b));
+		const Ctx4 x{tipmask, mats, P, C, c, valid ? k0 : P - 1};
+		const int k = x.k;
+		const d4 a = child_value(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
+		const d4 b = child_value(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
+		d4 out = mul4(matvec4(x.M(op.left), a), matvec4(x.M(op.right), b));
 		double sf = 0.0;
 		if (SCALE) {  // SingleTreeLikelihood_scalePartials (treelikelihood.c:1790-1836): max over categories and states
 			double *xb = sh + (q & 1) * xsz;
@@ -201,9 +229,9 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict
 				out = d4{out.x / m, out.y / m, out.z / m, out.w / m};
 				sf = log(m);
 			}
-			if (!ltip) sf += lscale[(size_t)(op.left - T) * P + k];
-			if (!rtip) sf += lscale[(size_t)(op.right - T) * P + k];
-			if (c == 0 && valid) lscale[(size_t)(op.parent - T) * P + k] = sf;
+			if (op.kind_left == CH_CORE) sf += lscale[(size_t)op.core_left * P + k];
+			if (op.kind_right == CH_CORE) sf += lscale[(size_t)op.core_right * P + k];
+			if (c == 0 && valid) lscale[(size_t)op.core_parent * P + k] = sf;
 		}
 		if (valid) store4(dst + (size_t)k * 4, out);
 		if (ROOT) {  // integrate_partials + node_log_likelihoods + weighted sum (treelikelihood.c:1473-1487)
@@ -247,59 +275,91 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict
 //   num_lc = sum_i f_i u_l,i (Q bl)_i     since (dP/dt) p = Q P p     (treelikelihood.c:2846-2939), f = 1 if FOLD else pi
 //   g[l][c] += w_k num_lc / L_k.  Unscaled: w_k / L_k comes from the root kernel.  Rescaled: L_k in this branch's
 //   units = sum_c' w_c' den_c' (COMPAT: den_c alone, treelikelihood.c:2851-2870)
+// A fringe child continues in registers: its upper is pushed through its cherry (and inner cherry), producing the
+// gradients of the 2-4 branches inside it (accumulators e[0..3]).
 // upper: slot s at upper + s * C*P*4.  gpart: [(N*C)][nblk] per-block partial sums.
-// dynamic LDS: 6 * G*C*64 doubles (three double-buffered exchanges) + 2*G*C doubles (reduction)
+// dynamic LDS: SCALE: 6 * G*C*64 doubles (three double-buffered exchanges); then NACC * waves * 64 doubles (reduction)
+
+constexpr int NACC = 10;  // gradient accumulators per thread: 2 children + 4 + 4 fringe branches
+
+struct Grad4 {
+	cptr Q;
+	d4 f;
+	double wl;
+	// w_k / L_k * sum_i f_i u_i (Q b)_i
+	__device__ __forceinline__ double term(const d4 &u, const d4 &b) const { return wl * dot4(mul4(f, u), matvec4(opaque(Q), b)); }
+};
+
+// push upper `u` of a fringe child (node `node`) down to its inner branches; e[0..3] accumulate
+//   CH_CHERRY     : e0 -> t0, e1 -> t1
+//   CH_CHERRY_TIP : e0 -> t0, e1 -> t1 (inside the inner cherry), e2 -> inner, e3 -> t2
+__device__ __forceinline__ void descend_fringe(const Ctx4 &x, const Grad4 &gr, int kind, int node, int t0, int t1, int t2, int inner, const d4 &u,
+                                               double (&e)[4]) {
+	const d4 a2 = matvec4(x.M(node), u);
+	const d4 b0 = matvec4(x.M(t0), x.tip(t0)), b1 = matvec4(x.M(t1), x.tip(t1));
+	if (kind == CH_CHERRY) {
+		e[0] += gr.term(mul4(a2, b1), b0);
+		e[1] += gr.term(mul4(a2, b0), b1);
+		return;
+	}
+	const d4 bn = matvec4(x.M(inner), mul4(b0, b1));
+	const d4 b2 = matvec4(x.M(t2), x.tip(t2));
+	const d4 un = mul4(a2, b2);
+	e[2] += gr.term(un, bn);
+	e[3] += gr.term(mul4(a2, bn), b2);
+	const d4 a3 = matvec4(x.M(inner), un);
+	e[0] += gr.term(mul4(a3, b1), b0);
+	e[1] += gr.term(mul4(a3, b0), b1);
+}
+
 template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
 __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
-                                                            const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
-                                                            double *__restrict__ upper, const double *__restrict__ mats,
-                                                            const double *__restrict__ Q, const double *__restrict__ freqs,
-                                                            const double *__restrict__ props, const double *__restrict__ weights,
-                                                            const double *__restrict__ w_over_L, double *__restrict__ gpart, int nblk) {
+                                                        const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
+                                                        double *__restrict__ upper, const double *__restrict__ mats,
+                                                        const double *__restrict__ Q, const double *__restrict__ freqs,
+                                                        const double *__restrict__ props, const double *__restrict__ weights,
+                                                        const double *__restrict__ w_over_L, double *__restrict__ gpart, int nblk) {
 	extern __shared__ double sh[];
 	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const NodeOp op = ops[blockIdx.y];
 	const size_t plane = (size_t)P * 4;
-	const bool ltip = op.left < T, rtip = op.right < T, proot = op.upper_slot_parent < 0;
-	const cptr Mp = as_const(mats + ((size_t)op.parent * C + c) * 16);
-	const cptr Ml = as_const(mats + ((size_t)op.left * C + c) * 16);
-	const cptr Mr = as_const(mats + ((size_t)op.right * C + c) * 16);
-	const cptr Qc = as_const(Q);
-	const double *pl = ltip ? nullptr : lower + ((size_t)(op.left - T) * C + c) * plane;
-	const double *pr = rtip ? nullptr : lower + ((size_t)(op.right - T) * C + c) * plane;
+	const bool proot = op.upper_slot_parent < 0;
 	const double *up = proot ? nullptr : upper + ((size_t)op.upper_slot_parent * C + c) * plane;
 	double *ul_dst = op.upper_slot_left < 0 ? nullptr : upper + ((size_t)op.upper_slot_left * C + c) * plane;
 	double *ur_dst = op.upper_slot_right < 0 ? nullptr : upper + ((size_t)op.upper_slot_right * C + c) * plane;
 	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
 	const d4 one = d4{1., 1., 1., 1.};
-	const d4 f = FOLD ? one : pi;
 	const int xsz = G * C * WAVE;
-	double gl = 0.0, gr = 0.0;
+	Grad4 gr{as_const(Q), FOLD ? one : pi, 0.0};
+	double gl = 0.0, grr = 0.0, el[4] = {0., 0., 0., 0.}, er[4] = {0., 0., 0., 0.};
 
 #pragma unroll 1
 	for (int q = 0; q < PPT; q++) {
 		const int k0 = ((blockIdx.x * PPT + q) * G + g) * WAVE + lane;
 		const bool valid = k0 < P;
-		const int k = valid ? k0 : P - 1;
-		const d4 vl = ltip ? mask4(tipmask[(size_t)op.left * P + k]) : load4(pl + (size_t)k * 4);
-		const d4 vr = rtip ? mask4(tipmask[(size_t)op.right * P + k]) : load4(pr + (size_t)k * 4);
-		const d4 a = proot ? (FOLD ? pi : one) : matvec4(opaque(Mp), load4(up + (size_t)k * 4));
-		const d4 bl = matvec4(opaque(Ml), vl);
-		const d4 br = matvec4(opaque(Mr), vr);
+		const Ctx4 x{tipmask, mats, P, C, c, valid ? k0 : P - 1};
+		const int k = x.k;
+		const d4 vl = child_value(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
+		const d4 vr = child_value(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
+		const d4 a = proot ? (FOLD ? pi : one) : matvec4(x.M(op.parent), load4(up + (size_t)k * 4));
+		const d4 bl = matvec4(x.M(op.left), vl);
+		const d4 br = matvec4(x.M(op.right), vr);
 		d4 ul = mul4(a, br), ur = mul4(a, bl);
-		const double den = dot4(mul4(f, a), mul4(bl, br));
-		const double numl = dot4(mul4(f, ul), matvec4(opaque(Qc), bl));
-		const double numr = dot4(mul4(f, ur), matvec4(opaque(Qc), br));
 		if (!SCALE) {
 			// unscaled: divide by the site likelihood formed at the root, like the reference (treelikelihood.c:2879);
 			// no cross-category exchange, no barrier, no division in this kernel
-			const double wl = valid ? w_over_L[k] : 0.0;
-			gl += wl * numl;
-			gr += wl * numr;
+			gr.wl = valid ? w_over_L[k] : 0.0;
+			gl += gr.term(ul, bl);
+			grr += gr.term(ur, br);
+			if (op.kind_left >= CH_CHERRY) descend_fringe(x, gr, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul, el);
+			if (op.kind_right >= CH_CHERRY) descend_fringe(x, gr, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur, er);
 		} else {
-			// rescaled: L_k underflows by construction, so the mixture likelihood is re-formed in this branch's scaled
-			// units from all categories' den (exchange through LDS); the scale factors cancel in num / D
+			// rescaled (always an unfused schedule): L_k underflows by construction, so the mixture likelihood is re-formed
+			// in this branch's scaled units from all categories' den (exchange through LDS); the scale factors cancel in num / D
+			const double den = dot4(mul4(gr.f, a), mul4(bl, br));
+			const double numl = dot4(mul4(gr.f, ul), matvec4(opaque(gr.Q), bl));
+			const double numr = dot4(mul4(gr.f, ur), matvec4(opaque(gr.Q), br));
 			double *xb = sh + (q & 1) * 3 * xsz;
 			const int xi = (g * C + c) * WAVE + lane;
 			xb[xi] = props[c] * den;
@@ -315,7 +375,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict
 			// num / L first: with COMPAT both can be denormal (a category that has underflowed) and 1 / den alone overflows
 			const double w = valid ? weights[k] : 0.0, d = COMPAT ? den : D;
 			gl += w * (numl / d);
-			gr += w * (numr / d);
+			grr += w * (numr / d);
 			// uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
 			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
 			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
@@ -323,22 +383,48 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict
 		if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
 		if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
 	}
-	// fixed-order reduction: lanes (shuffle) -> pattern groups (LDS) -> one slab entry per (child, category)
-	double *red = sh + (SCALE ? 6 * xsz : 0);  // the exchange buffers exist only in the rescaled variant
-	const double sl = wave_sum(gl), sr = wave_sum(gr);
-	if (lane == 0) {
-		red[(g * C + c) * 2] = sl;
-		red[(g * C + c) * 2 + 1] = sr;
+	// Fixed-order reduction over the workgroup's patterns: every wave parks its accumulators in LDS as [acc][lane];
+	// one lane per (wave, accumulator) adds the 64 entries in lane order; wave 0 of each category adds the pattern groups.
+	__syncthreads();  // SCALE: the exchange buffers may still be read
+	double *red = sh;
+	const int wv = g * C + c, nw = G * C;
+	const double accs[NACC] = {gl, grr, el[0], el[1], el[2], el[3], er[0], er[1], er[2], er[3]};
+#pragma unroll
+	for (int i = 0; i < NACC; i++) red[((size_t)wv * NACC + i) * WAVE + lane] = accs[i];
+	__syncthreads();
+	if (lane < NACC) {
+		const double *src = red + ((size_t)wv * NACC + lane) * WAVE;
+		double s0 = src[0], s1 = src[16], s2 = src[32], s3 = src[48];  // four chains of 16, then a fixed combine
+		for (int j = 1; j < 16; j++) {
+			s0 += src[j];
+			s1 += src[16 + j];
+			s2 += src[32 + j];
+			s3 += src[48 + j];
+		}
+		const double s = (s0 + s1) + (s2 + s3);
+		red[(size_t)nw * NACC * WAVE + wv * NACC + lane] = s;
 	}
 	__syncthreads();
-	if (lane == 0 && g == 0) {
-		double tl = red[c * 2], tr = red[c * 2 + 1];
-		for (int gg = 1; gg < G; gg++) {
-			tl += red[(gg * C + c) * 2];
-			tr += red[(gg * C + c) * 2 + 1];
+	if (g == 0 && lane < NACC) {
+		const double *tot = red + (size_t)nw * NACC * WAVE;
+		double s = tot[c * NACC + lane];
+		for (int gg = 1; gg < G; gg++) s += tot[(gg * C + c) * NACC + lane];
+		// accumulator -> gradient row (node id); -1 = unused for this op
+		const int kl = op.kind_left, kr = op.kind_right;
+		int node = -1;
+		switch (lane) {
+			case 0: node = op.left; break;
+			case 1: node = op.right; break;
+			case 2: node = kl >= CH_CHERRY ? op.lt0 : -1; break;
+			case 3: node = kl >= CH_CHERRY ? op.lt1 : -1; break;
+			case 4: node = kl == CH_CHERRY_TIP ? op.linner : -1; break;
+			case 5: node = kl == CH_CHERRY_TIP ? op.lt2 : -1; break;
+			case 6: node = kr >= CH_CHERRY ? op.rt0 : -1; break;
+			case 7: node = kr >= CH_CHERRY ? op.rt1 : -1; break;
+			case 8: node = kr == CH_CHERRY_TIP ? op.rinner : -1; break;
+			case 9: node = kr == CH_CHERRY_TIP ? op.rt2 : -1; break;
 		}
-		gpart[((size_t)op.left * C + c) * nblk + blockIdx.x] = tl;
-		gpart[((size_t)op.right * C + c) * nblk + blockIdx.x] = tr;
+		if (node >= 0) gpart[((size_t)node * C + c) * nblk + blockIdx.x] = s;
 	}
 }
 
@@ -396,6 +482,10 @@ struct phyamd_engine {
 	std::vector<int> lower_level_off, upper_level_off;  // offsets into the op arrays, one past the last at the end
 	std::vector<int32_t> upper_slot;                    // node -> slot of its upper partial in the last schedule (-1 none)
 	int upper_slots = 0;
+	std::vector<int32_t> core_index;  // node -> index of its stored lower array (-1: tip or fused)
+	int core_count = 0;
+	bool fusion_enabled = true, fused = false;
+	size_t lower_alloc_cores = 0;
 
 	// device memory
 	uint8_t *d_tipmask = nullptr;
@@ -476,24 +566,70 @@ int build_schedule(phyamd_engine *e) {
 		}
 	}
 	if ((int)order.size() != N) return fail(PHYAMD_EINVAL, "topology is not a single binary tree over all %d nodes", N);
-	// height (tips = 0), children before parents: reverse of the pre-order list
+	// Fringe classification (4-state, unscaled, not keep_partials): cherries (tip, tip) and cherry + tip nodes are fused
+	// into their parent's work and never stored.  Everything else that is internal is a "core" node with an array in HBM.
+	const bool fuse = e->fusion_enabled && !e->generic && !e->keep_partials && !e->scaling_on;
+	e->fused = fuse;
+	std::vector<int> kind(N, CH_CORE);
+	for (int n = 0; n < T; n++) kind[n] = CH_TIP;
+	if (fuse) {
+		for (int i = N - 1; i >= 0; i--) {  // children before parents
+			const int n = order[i];
+			if (n < T || n == e->root) continue;
+			const int l = e->left[n], r = e->right[n];
+			if (l < T && r < T) kind[n] = CH_CHERRY;
+			else if ((l < T && kind[r] == CH_CHERRY) || (r < T && kind[l] == CH_CHERRY)) kind[n] = CH_CHERRY_TIP;
+		}
+	}
+	// stored lower arrays: core nodes in id order
+	e->core_index.assign(N, -1);
+	e->core_count = 0;
+	for (int n = T; n < N; n++)
+		if (kind[n] == CH_CORE) e->core_index[n] = e->core_count++;
+	auto describe = [&](int ch, int32_t &k, int32_t &core, int32_t &t0, int32_t &t1, int32_t &t2, int32_t &inner) {
+		k = kind[ch];
+		core = e->core_index[ch];
+		t0 = t1 = t2 = inner = -1;
+		if (k == CH_CHERRY) {
+			t0 = e->left[ch];
+			t1 = e->right[ch];
+		} else if (k == CH_CHERRY_TIP) {
+			const int l = e->left[ch], r = e->right[ch];
+			inner = l < T ? r : l;
+			t2 = l < T ? l : r;
+			t0 = e->left[inner];
+			t1 = e->right[inner];
+		}
+	};
+	auto make_op = [&](int n) {
+		NodeOp op{};
+		op.parent = n;
+		op.left = e->left[n];
+		op.right = e->right[n];
+		op.upper_slot_parent = op.upper_slot_left = op.upper_slot_right = -1;
+		op.core_parent = e->core_index[n];
+		describe(op.left, op.kind_left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner);
+		describe(op.right, op.kind_right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner);
+		return op;
+	};
+	// height over the core tree (tips and fused nodes = 0), children before parents: reverse of the pre-order list
 	std::vector<int> height(N, 0);
 	int H = 0, Dmax = 0;
 	for (int i = N - 1; i >= 0; i--) {
 		const int n = order[i];
-		if (n >= T) height[n] = 1 + std::max(height[e->left[n]], height[e->right[n]]);
+		if (kind[n] == CH_CORE) height[n] = 1 + std::max(height[e->left[n]], height[e->right[n]]);
 		H = std::max(H, height[n]);
 		Dmax = std::max(Dmax, depth[n]);
 	}
-	// lower levels: internal nodes by height 1..H (the root has the largest height and is alone on its level)
+	// lower levels: core nodes by height 1..H (the root has the largest height and is alone on its level)
 	e->lower_ops.clear();
 	e->lower_level_off.assign(1, 0);
 	for (int h = 1; h <= H; h++) {
 		for (int n = T; n < N; n++)
-			if (height[n] == h) e->lower_ops.push_back(NodeOp{n, e->left[n], e->right[n], -1, -1, -1});
+			if (kind[n] == CH_CORE && height[n] == h) e->lower_ops.push_back(make_op(n));
 		e->lower_level_off.push_back((int)e->lower_ops.size());
 	}
-	// upper levels: parents by depth 0..Dmax-1.  Upper partials of depth-d nodes are only read while
+	// upper levels: core parents by depth 0..Dmax-1.  Upper partials of depth-d nodes are only read while
 	// depth d+1 is produced, so slots are recycled two levels later (keep_partials: slot = own index).
 	e->upper_ops.clear();
 	e->upper_level_off.assign(1, 0);
@@ -507,11 +643,12 @@ int build_schedule(phyamd_engine *e) {
 			slots_of_depth[d - 1].clear();
 		}
 		for (int n = T; n < N; n++) {
-			if (depth[n] != d) continue;
-			NodeOp op{n, e->left[n], e->right[n], n == e->root ? -1 : e->upper_slot[n], -1, -1};
+			if (depth[n] != d || kind[n] != CH_CORE) continue;
+			NodeOp op = make_op(n);
+			op.upper_slot_parent = n == e->root ? -1 : e->upper_slot[n];
 			for (int side = 0; side < 2; side++) {
 				const int ch = side ? e->right[n] : e->left[n];
-				if (ch < T && !e->keep_partials) continue;  // tips' uppers are never read again
+				if (kind[ch] != CH_CORE && !e->keep_partials) continue;  // uppers of tips and fused nodes stay in registers
 				int s;
 				if (e->keep_partials) s = ch;
 				else if (!free_slots.empty()) {
@@ -528,6 +665,18 @@ int build_schedule(phyamd_engine *e) {
 		e->upper_level_off.push_back((int)e->upper_ops.size());
 	}
 	e->upper_slots = e->keep_partials ? N : next_slot;
+	return PHYAMD_OK;
+}
+
+int ensure_lower_storage(phyamd_engine *e) {
+	const size_t need = (size_t)std::max(1, e->core_count);
+	if (e->d_lower && e->lower_alloc_cores >= need) return PHYAMD_OK;
+	dev_free(e, &e->d_lower, e->lower_alloc_cores * node_partial_doubles(e));
+	dev_free(e, &e->d_lscale, e->lower_alloc_cores * (size_t)e->P);
+	e->lower_alloc_cores = 0;
+	int rc = dev_alloc(e, &e->d_lower, need * node_partial_doubles(e));
+	if (rc) return rc;
+	e->lower_alloc_cores = need;
 	return PHYAMD_OK;
 }
 
@@ -559,7 +708,7 @@ int ensure_upper_storage(phyamd_engine *e) {
 
 int ensure_scaling_storage(phyamd_engine *e) {
 	if (e->d_lscale) return PHYAMD_OK;
-	return dev_alloc(e, &e->d_lscale, (size_t)(e->N - e->T) * e->P);
+	return dev_alloc(e, &e->d_lscale, e->lower_alloc_cores * (size_t)e->P);
 }
 
 int check_ready(phyamd_engine *e) {
@@ -623,7 +772,8 @@ int launch_lower_w(phyamd_engine *e) {
 template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
 int launch_upper_levels(phyamd_engine *e) {
 	const int levels = (int)e->upper_level_off.size() - 1;
-	const size_t lds = sizeof(double) * ((SCALE ? (size_t)6 * e->G * e->C * WAVE : 0) + 2 * e->G * e->C);
+	const size_t nw = (size_t)e->G * e->C;
+	const size_t lds = sizeof(double) * std::max<size_t>(SCALE ? 6 * nw * WAVE : 0, nw * NACC * WAVE + nw * NACC);
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
@@ -712,6 +862,15 @@ int launch_upper(phyamd_engine *e, int flags) {
 	return waves <= 4 ? launch_upper_w<4>(e, flags) : waves <= 8 ? launch_upper_w<8>(e, flags) : launch_upper_w<16>(e, flags);
 }
 
+int rebuild_schedule(phyamd_engine *e) {
+	int rc;
+	if ((rc = build_schedule(e))) return rc;
+	if ((rc = upload_schedule(e))) return rc;
+	if ((rc = ensure_lower_storage(e))) return rc;
+	e->upper_valid = false;
+	return PHYAMD_OK;
+}
+
 void record(phyamd_engine *e, int i) {
 	if (e->profiling) (void)hipEventRecord(e->ev[i], e->stream);
 }
@@ -736,6 +895,7 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 		HIP_TRY(hipStreamSynchronize(e->stream));
 		if (!std::isinf(e->h_result[0])) break;
 		e->scaling_on = true;
+		if ((rc = rebuild_schedule(e))) return rc;  // rescaling runs the unfused schedule (every internal node stored)
 		if ((rc = ensure_scaling_storage(e))) return rc;
 	}
 	record(e, 2);
@@ -831,6 +991,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 		e->own_stream = true;
 	}
 	e->scaling_on = cfg->rescale == PHYAMD_RESCALE_ALWAYS;
+	if (const char *env = std::getenv("PHYAMD_FUSE")) e->fusion_enabled = std::atoi(env) != 0;  // A/B switch for the fringe fusion
 	if (e->C > MAX_WAVES) {
 		delete e;
 		return fail(PHYAMD_EUNSUPPORTED, "category_count %d exceeds %d (one wave per category)", cfg->category_count, MAX_WAVES);
@@ -849,14 +1010,14 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	const size_t np = node_partial_doubles(e);
 	const size_t msz = (size_t)e->N * e->C * e->S * e->S;
 	if (cfg->max_device_bytes > 0) {
-		const double need = 8.0 * ((double)(e->N - e->T) * np + 2.0 * np) + (double)e->T * e->P;
+		const double need = 8.0 * (0.5 * (double)(e->N - e->T) * np + 2.0 * np) + (double)e->T * e->P;
 		if (need > (double)cfg->max_device_bytes)
 			return bail(fail(PHYAMD_ENOMEM, "engine needs >= %.3g bytes, max_device_bytes is %lld (pattern tiling is not built in this revision)", need,
 			                 (long long)cfg->max_device_bytes));
 	}
 	int rc;
 	if ((rc = dev_alloc(e, &e->d_tipmask, (size_t)e->T * e->P))) return bail(rc);
-	if ((rc = dev_alloc(e, &e->d_lower, (size_t)(e->N - e->T) * np))) return bail(rc);
+	// d_lower is sized by the schedule (stored "core" nodes only): ensure_lower_storage
 	if ((rc = dev_alloc(e, &e->d_mats, msz))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_dmats, msz))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_model, (size_t)e->S + 2 * e->S * e->S))) return bail(rc);
@@ -994,6 +1155,7 @@ int phyamd_set_topology(phyamd_engine *e, const int32_t *left, const int32_t *ri
 		return rc;
 	}
 	if ((rc = upload_schedule(e))) return rc;
+	if ((rc = ensure_lower_storage(e))) return rc;
 	e->have_topology = true;
 	e->matrices_dirty = true;
 	e->upper_valid = false;
@@ -1191,7 +1353,9 @@ int phyamd_get_partials(phyamd_engine *e, int node, int upper, double *out) {
 					out[((size_t)c * e->P + k) * S + s] = e->generic ? ((mask[k] >= S || mask[k] == s) ? 1.0 : 0.0) : ((mask[k] >> s) & 1 ? 1.0 : 0.0);
 		return PHYAMD_OK;
 	}
-	const double *src = upper ? e->d_upper + (size_t)e->upper_slot[node] * np : e->d_lower + (size_t)(node - e->T) * np;
+	if (!upper && e->core_index[node] < 0)
+		return fail(PHYAMD_EINVAL, "node %d is fused into its parent (cherry / cherry+tip) and not stored: phyamd_set_keep_partials(1) first", node);
+	const double *src = upper ? e->d_upper + (size_t)e->upper_slot[node] * np : e->d_lower + (size_t)e->core_index[node] * np;
 	if (e->generic) {  // planes [C][S][Pp] -> the reference's [C][P][S]
 		double *tmp = nullptr;
 		const size_t cnt = (size_t)e->C * e->P * e->S;
@@ -1236,8 +1400,7 @@ int phyamd_set_keep_partials(phyamd_engine *e, int on) {
 	if (e->have_topology) {
 		int rc;
 		if ((rc = bind_device(e))) return rc;
-		if ((rc = build_schedule(e))) return rc;
-		if ((rc = upload_schedule(e))) return rc;
+		if ((rc = rebuild_schedule(e))) return rc;
 	}
 	return PHYAMD_OK;
 }

@@ -38,6 +38,8 @@ def test_golden_log_likelihood(case):
         assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
         np.testing.assert_allclose(e.pattern_log_likelihoods(), gold["pattern_lk"], rtol=1e-11, atol=1e-11)
         if "partials_root" in gold:
+            e.set_keep_partials(True)  # store every node (the default schedule fuses cherries into their parents)
+            assert abs(e.log_likelihood() - lnl) <= 1e-12 * abs(lnl)
             np.testing.assert_allclose(e.partials(gold["root"]), gold["partials_root"], rtol=1e-9, atol=1e-300)
             np.testing.assert_allclose(e.partials(gold["tip_count"]), gold["partials_first_internal"], rtol=1e-9, atol=1e-300)
         if "pt" in gold:
@@ -58,9 +60,12 @@ def test_golden_branch_gradient(case, fold):
     pb = oracle_problem(case, gold)
     flags = (GRAD_FOLD_ROOT_FREQS if fold else 0) | (GRAD_COMPAT_SCALED if gold["rescaled"] and gold["category_count"] > 1 else 0)
     with engine_from_problem(pb, rescale=_rescale(case), tip_mode=_tip_mode(case)) as e:
-        e.set_keep_partials(True)
+        lnl_f, cg_f = e.gradient(flags)  # default schedule: cherries / cherry+tip nodes fused into their parents
+        e.set_keep_partials(True)        # unfused schedule, every node stored
         lnl, cg = e.gradient(flags)
-        assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+        assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"]) and abs(lnl_f - lnl) <= 1e-12 * abs(lnl)
+        both = np.isfinite(cg) & np.isfinite(cg_f)
+        assert np.abs(cg[both] - cg_f[both]).max() <= 1e-10 * max(1.0, np.abs(cg[both]).max())
         g = po.branch_gradient_from_cat(cg, gold["cat_rates"], gold["cat_proportions"], zero_node=gold["right"][gold["root"]])
         # the reference's rescaled multi-category gradient is NaN wherever one category underflows (60 % of the
         # branches of gtr_g4_t700_autorescale); the compat mode underflows in slightly different places
@@ -98,6 +103,10 @@ def _compare_with_oracle(pb, rescale, flags=0, tip_mode="states", check_partials
     ref = pb.gradient(want_partials=check_partials)
     with engine_from_problem(pb, rescale=rescale, tip_mode=tip_mode) as e:
         if check_partials:
+            # first the default (fused) schedule, then the one that stores every node
+            lnl_f, cg_f = e.gradient(flags)
+            assert abs(lnl_f - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+            assert np.abs(cg_f - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
             e.set_keep_partials(True)
         lnl_only = e.log_likelihood()
         lnl, cg = e.gradient(flags)
@@ -216,6 +225,28 @@ def test_full_size_properties():
             fd = (up - dn) / (2 * h)
             assert abs(fd - bg[n]) <= 1e-4 * max(1.0, abs(bg[n])), (n, fd, bg[n])
         e.set_branch_lengths(tree.length)
+
+
+def test_fusion_switch_and_memory():
+    """PHYAMD_FUSE=0 gives the unfused schedule; results agree and the fused engine stores about half the arrays."""
+    import os
+    pb = random_problem(200, 3000, 4, seed=31, gaps=0.02)
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        lnl_f, cg_f = e.gradient()
+        e.set_profiling(True)
+        bytes_f = e.profile()["device_bytes"]
+        with pytest.raises(EngineError):
+            e.partials(int(np.argmax((pb.left[pb.T:] < pb.T) & (pb.right[pb.T:] < pb.T))) + pb.T)  # a cherry: not stored
+    os.environ["PHYAMD_FUSE"] = "0"
+    try:
+        with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+            lnl_u, cg_u = e.gradient()
+            bytes_u = e.profile()["device_bytes"]
+    finally:
+        del os.environ["PHYAMD_FUSE"]
+    assert abs(lnl_f - lnl_u) <= 1e-12 * abs(lnl_u)
+    assert np.abs(cg_f - cg_u).max() <= 1e-10 * max(1.0, np.abs(cg_u).max())
+    assert bytes_f < 0.75 * bytes_u
 
 
 def test_error_behaviour():
