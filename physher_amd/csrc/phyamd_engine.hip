@@ -108,6 +108,9 @@ __device__ __forceinline__ d4 matvec4(cptr M, const d4 &v) {
 	r.y = M[4] * v.x + M[5] * v.y + M[6] * v.z + M[7] * v.w;
 	r.z = M[8] * v.x + M[9] * v.y + M[10] * v.z + M[11] * v.w;
 	r.w = M[12] * v.x + M[13] * v.y + M[14] * v.z + M[15] * v.w;
+	// Fence the scheduler: without it every s_load_dwordx16 of a basic block is hoisted to its top (10 matrices = 320
+	// SGPRs in the fringe paths) and the overflow is parked in VGPR lanes (v_writelane / v_readlane around every use).
+	__builtin_amdgcn_sched_barrier(0);
 	return r;
 }
 
@@ -286,34 +289,35 @@ struct Grad4 {
 	cptr Q;
 	d4 f;
 	double wl;
-	// w_k / L_k * sum_i f_i u_i (Q b)_i
-	__device__ __forceinline__ double term(const d4 &u, const d4 &b) const { return wl * dot4(mul4(f, u), matvec4(opaque(Q), b)); }
+	double *acc;  // this thread's NACC accumulators in LDS: acc[i * WAVE] (lane-interleaved, conflict-free)
+	// acc[i] += w_k / L_k * sum_i f_i u_i (Q b)_i
+	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const {
+		acc[i * WAVE] += wl * dot4(mul4(f, u), matvec4(opaque(Q), b));
+	}
 };
 
-// push upper `u` of a fringe child (node `node`) down to its inner branches; e[0..3] accumulate
-//   CH_CHERRY     : e0 -> t0, e1 -> t1
-//   CH_CHERRY_TIP : e0 -> t0, e1 -> t1 (inside the inner cherry), e2 -> inner, e3 -> t2
-__device__ __forceinline__ void descend_fringe(const Ctx4 &x, const Grad4 &gr, int kind, int node, int t0, int t1, int t2, int inner, const d4 &u,
-                                               double (&e)[4]) {
-	const d4 a2 = matvec4(x.M(node), u);
+// push upper `u` of a fringe child (node `node`) down to its inner branches; accumulators base..base+3:
+//   CH_CHERRY     : +0 -> t0, +1 -> t1
+//   CH_CHERRY_TIP : +0 -> t0, +1 -> t1 (inside the inner cherry), +2 -> inner, +3 -> t2
+// Ordered so that few vectors are live at once (the kernel is register-limited).
+__device__ __forceinline__ void descend_fringe(const Ctx4 &x, const Grad4 &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
+                                               const d4 &u) {
 	const d4 b0 = matvec4(x.M(t0), x.tip(t0)), b1 = matvec4(x.M(t1), x.tip(t1));
-	if (kind == CH_CHERRY) {
-		e[0] += gr.term(mul4(a2, b1), b0);
-		e[1] += gr.term(mul4(a2, b0), b1);
-		return;
+	d4 a2 = matvec4(x.M(node), u);
+	if (kind == CH_CHERRY_TIP) {
+		const d4 bn = matvec4(x.M(inner), mul4(b0, b1));
+		const d4 b2 = matvec4(x.M(t2), x.tip(t2));
+		const d4 un = mul4(a2, b2);
+		gr.add(base + 2, un, bn);
+		gr.add(base + 3, mul4(a2, bn), b2);
+		a2 = matvec4(x.M(inner), un);  // now the upper message entering the inner cherry
 	}
-	const d4 bn = matvec4(x.M(inner), mul4(b0, b1));
-	const d4 b2 = matvec4(x.M(t2), x.tip(t2));
-	const d4 un = mul4(a2, b2);
-	e[2] += gr.term(un, bn);
-	e[3] += gr.term(mul4(a2, bn), b2);
-	const d4 a3 = matvec4(x.M(inner), un);
-	e[0] += gr.term(mul4(a3, b1), b0);
-	e[1] += gr.term(mul4(a3, b0), b1);
+	gr.add(base + 0, mul4(a2, b1), b0);
+	gr.add(base + 1, mul4(a2, b0), b1);
 }
 
 template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
-__global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
+__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? 4 : 1) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
                                                         const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
                                                         double *__restrict__ upper, const double *__restrict__ mats,
                                                         const double *__restrict__ Q, const double *__restrict__ freqs,
@@ -331,8 +335,12 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict
 	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
 	const d4 one = d4{1., 1., 1., 1.};
 	const int xsz = G * C * WAVE;
-	Grad4 gr{as_const(Q), FOLD ? one : pi, 0.0};
-	double gl = 0.0, grr = 0.0, el[4] = {0., 0., 0., 0.}, er[4] = {0., 0., 0., 0.};
+	// gradient accumulators live in LDS (one column per thread), not in registers: the kernel is VGPR-limited
+	const int wv = g * C + c, nw = G * C;
+	double *red = sh + (SCALE ? 6 * xsz : 0);
+	Grad4 gr{as_const(Q), FOLD ? one : pi, 0.0, red + (size_t)wv * NACC * WAVE + lane};
+#pragma unroll
+	for (int i = 0; i < NACC; i++) gr.acc[i * WAVE] = 0.0;
 
 #pragma unroll 1
 	for (int q = 0; q < PPT; q++) {
@@ -350,10 +358,13 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict
 			// unscaled: divide by the site likelihood formed at the root, like the reference (treelikelihood.c:2879);
 			// no cross-category exchange, no barrier, no division in this kernel
 			gr.wl = valid ? w_over_L[k] : 0.0;
-			gl += gr.term(ul, bl);
-			grr += gr.term(ur, br);
-			if (op.kind_left >= CH_CHERRY) descend_fringe(x, gr, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul, el);
-			if (op.kind_right >= CH_CHERRY) descend_fringe(x, gr, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur, er);
+			gr.add(0, ul, bl);
+			gr.add(1, ur, br);
+			if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
+			if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
+			if (op.kind_left >= CH_CHERRY) descend_fringe(x, gr, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
+			if (op.kind_right >= CH_CHERRY) descend_fringe(x, gr, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
+			continue;
 		} else {
 			// rescaled (always an unfused schedule): L_k underflows by construction, so the mixture likelihood is re-formed
 			// in this branch's scaled units from all categories' den (exchange through LDS); the scale factors cancel in num / D
@@ -374,8 +385,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict
 			}
 			// num / L first: with COMPAT both can be denormal (a category that has underflowed) and 1 / den alone overflows
 			const double w = valid ? weights[k] : 0.0, d = COMPAT ? den : D;
-			gl += w * (numl / d);
-			grr += w * (numr / d);
+			gr.acc[0] += w * (numl / d);
+			gr.acc[WAVE] += w * (numr / d);
 			// uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
 			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
 			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
@@ -383,14 +394,8 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_upper4(const NodeOp *__restrict
 		if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
 		if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
 	}
-	// Fixed-order reduction over the workgroup's patterns: every wave parks its accumulators in LDS as [acc][lane];
+	// Fixed-order reduction over the workgroup's patterns: the accumulators sit in LDS as [wave][acc][lane];
 	// one lane per (wave, accumulator) adds the 64 entries in lane order; wave 0 of each category adds the pattern groups.
-	__syncthreads();  // SCALE: the exchange buffers may still be read
-	double *red = sh;
-	const int wv = g * C + c, nw = G * C;
-	const double accs[NACC] = {gl, grr, el[0], el[1], el[2], el[3], er[0], er[1], er[2], er[3]};
-#pragma unroll
-	for (int i = 0; i < NACC; i++) red[((size_t)wv * NACC + i) * WAVE + lane] = accs[i];
 	__syncthreads();
 	if (lane < NACC) {
 		const double *src = red + ((size_t)wv * NACC + lane) * WAVE;
@@ -773,7 +778,7 @@ template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
 int launch_upper_levels(phyamd_engine *e) {
 	const int levels = (int)e->upper_level_off.size() - 1;
 	const size_t nw = (size_t)e->G * e->C;
-	const size_t lds = sizeof(double) * std::max<size_t>(SCALE ? 6 * nw * WAVE : 0, nw * NACC * WAVE + nw * NACC);
+	const size_t lds = sizeof(double) * ((SCALE ? 6 * nw * WAVE : 0) + nw * NACC * WAVE + nw * NACC);
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
