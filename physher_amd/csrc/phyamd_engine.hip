@@ -749,12 +749,14 @@ dim3 block_dims(const phyamd_engine *e) { return dim3(WAVE, e->C, e->G); }
 template <int WAVES, bool SCALE>
 int launch_lower_levels(phyamd_engine *e) {
 	const int levels = (int)e->lower_level_off.size() - 1;
+	int launched = 0;
 	const size_t lds = sizeof(double) * ((size_t)4 * e->G * e->C * WAVE + e->G);
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->lower_level_off[lv], cnt = e->lower_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		const bool is_root = lv == levels - 1;
 		dim3 grid(e->nblk, cnt);
+		launched++;
 		if (is_root)
 			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, true>), grid, block_dims(e), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->C,
 			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
@@ -765,7 +767,7 @@ int launch_lower_levels(phyamd_engine *e) {
 			                   e->d_lnl_part);
 	}
 	HIP_TRY(hipGetLastError());
-	e->prof.lower_launches = levels;
+	e->prof.lower_launches = launched;
 	return PHYAMD_OK;
 }
 
@@ -777,18 +779,20 @@ int launch_lower_w(phyamd_engine *e) {
 template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
 int launch_upper_levels(phyamd_engine *e) {
 	const int levels = (int)e->upper_level_off.size() - 1;
+	int launched = 0;
 	const size_t nw = (size_t)e->G * e->C;
 	const size_t lds = sizeof(double) * ((SCALE ? 6 * nw * WAVE : 0) + nw * NACC * WAVE + nw * NACC);
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		dim3 grid(e->nblk, cnt);
+		launched++;
 		hipLaunchKernelGGL((k_upper4<WAVES, SCALE, FOLD, COMPAT>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C,
 		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_wl, e->d_gpart,
 		                   e->nblk);
 	}
 	HIP_TRY(hipGetLastError());
-	e->prof.upper_launches = levels;
+	e->prof.upper_launches = launched;
 	return PHYAMD_OK;
 }
 
