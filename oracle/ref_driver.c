@@ -59,6 +59,8 @@ typedef struct {
 	int categories;
 	double alpha;
 	int tipstates, sse, rescale, generic_kernels;
+	char sitedist[32]; /* gamma | weibull | discrete (+I only) */
+	double pinv, mu;   /* < 0: absent */
 } spec_t;
 
 static int parse_list(const char *s, double *out, int max) {
@@ -77,6 +79,9 @@ static void read_spec(const char *path, spec_t *sp) {
 	sp->alpha = 0.5;
 	sp->tipstates = 0;
 	sp->sse = 1;
+	strcpy(sp->sitedist, "gamma");
+	sp->pinv = -1;
+	sp->mu = -1;
 	FILE *f = fopen(path, "r");
 	if (!f) { fprintf(stderr, "cannot open spec %s\n", path); exit(2); }
 	char key[64], val[4096];
@@ -93,6 +98,9 @@ static void read_spec(const char *path, spec_t *sp) {
 		else if (!strcmp(key, "sse")) sp->sse = atoi(val);
 		else if (!strcmp(key, "rescale")) sp->rescale = atoi(val);
 		else if (!strcmp(key, "generic_kernels")) sp->generic_kernels = atoi(val);
+		else if (!strcmp(key, "sitedist")) strcpy(sp->sitedist, val);
+		else if (!strcmp(key, "pinv")) sp->pinv = atof(val);
+		else if (!strcmp(key, "mu")) sp->mu = atof(val);
 		else { fprintf(stderr, "unknown spec key %s\n", key); exit(2); }
 	}
 	fclose(f);
@@ -161,13 +169,21 @@ static built_t build_from_spec(const spec_t *sp) {
 	js[0] = 0;
 	append(&js, &len, &cap, "{\"id\":\"treelikelihood\",\"type\":\"treelikelihood\",\"sse\":%s,\"tipstates\":%s,\"sitepattern\":\"&patterns\",\"tree\":\"&tree\",",
 	       sp->sse ? "true" : "false", sp->tipstates ? "true" : "false");
-	/* site model */
+	/* site model (sitemodel.c:1056-1246): "categories" counts the variable classes; a 2-simplex of proportions adds +I */
 	append(&js, &len, &cap, "\"sitemodel\":{\"id\":\"sitemodel\",\"type\":\"sitemodel\"");
-	if (sp->categories > 1) {
-		append(&js, &len, &cap,
-		       ",\"distribution\":{\"distribution\":\"gamma\",\"categories\":%d,\"parameters\":{\"alpha\":{\"id\":\"alpha\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}}}",
-		       sp->categories, sp->alpha);
+	if (sp->categories > 1 || sp->pinv >= 0) {
+		const bool discrete = !strcmp(sp->sitedist, "discrete");
+		append(&js, &len, &cap, ",\"distribution\":{\"distribution\":\"%s\"", sp->sitedist);
+		if (!discrete)
+			append(&js, &len, &cap,
+			       ",\"categories\":%d,\"parameters\":{\"alpha\":{\"id\":\"alpha\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}}",
+			       sp->categories, sp->alpha);
+		if (sp->pinv >= 0)
+			append(&js, &len, &cap, ",\"proportions\":{\"id\":\"pinv\",\"type\":\"Simplex\",\"values\":[%.17g,%.17g]}", sp->pinv, 1.0 - sp->pinv);
+		append(&js, &len, &cap, "}");
 	}
+	if (sp->mu >= 0)
+		append(&js, &len, &cap, ",\"mu\":{\"id\":\"mu\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}", sp->mu);
 	append(&js, &len, &cap, "}");
 	if (!codon) {
 		append(&js, &len, &cap, ",\"substitutionmodel\":{\"id\":\"sm\",\"type\":\"substitutionmodel\",\"model\":\"%s\",\"datatype\":\"%s\"", sp->model, sp->datatype);
@@ -291,6 +307,9 @@ static void dump_common(FILE *o, Model *mlike) {
 	jarr(o, "cat_rates", rates, C, true);
 	free(rates);
 	jarr(o, "cat_proportions", tlk->sm->get_proportions(tlk->sm), C, true);
+	jarr(o, "cat_rates_without_mu", tlk->sm->cat_rates, C, true);
+	fprintf(o, "\"site_rate_parameters\":%d,\"site_has_pinv\":%s,\"site_has_mu\":%s,\n", (int)Parameters_count(tlk->sm->rates),
+	        tlk->sm->proportions ? "true" : "false", tlk->sm->mu ? "true" : "false");
 	jarr(o, "frequencies", tlk->get_root_frequencies(tlk), S, true);
 	jarr(o, "eval", tlk->m->eigendcmp->eval, S, true);
 	{

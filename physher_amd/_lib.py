@@ -55,6 +55,7 @@ SYMBOLS = [
     ("phyamd_gradient", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), _P]),
     ("phyamd_branch_gradient", C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), _P]),
     ("phyamd_gradient_device", C.c_int, [_P, C.c_int, _P]),
+    ("phyamd_root_invariant_term", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("phyamd_synchronize", C.c_int, [_P]),
     ("phyamd_get_pattern_log_likelihoods", C.c_int, [_P, _P]),
     ("phyamd_get_partials", C.c_int, [_P, C.c_int, C.c_int, _P]),

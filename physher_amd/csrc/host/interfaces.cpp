@@ -444,17 +444,23 @@ const std::vector<unsigned char> &TreeLikelihoodInterface::PatternStates() const
 void TreeLikelihoodInterface::RequestGradient(std::vector<TreeLikelihoodGradientFlags> flags) {
 	int f = 0;
 	for (auto x : flags) f |= (int)x;
-	if (f == 0) {  // TreeLikelihood_initialize_gradient(flags = 0): whatever this build can differentiate
+	const phyamd::SiteModel &smc = *siteModel_->GetModel();
+	const bool site_params = smc.dist != phyamd::RateDistribution::Constant || smc.has_pinv || smc.has_mu;
+	if (f == 0) {  // TreeLikelihood_initialize_gradient(flags = 0): whatever this build can differentiate (treelikelihood.c:255-270)
 		f = (int)TreeLikelihoodGradientFlags::TREE_HEIGHT;
+		if (site_params) f |= (int)TreeLikelihoodGradientFlags::SITE_MODEL;
 		if (branchModel_) f |= (int)TreeLikelihoodGradientFlags::BRANCH_MODEL;
 	}
-	const int built = (int)TreeLikelihoodGradientFlags::TREE_HEIGHT | (int)TreeLikelihoodGradientFlags::BRANCH_MODEL;
+	const int built = (int)TreeLikelihoodGradientFlags::TREE_HEIGHT | (int)TreeLikelihoodGradientFlags::BRANCH_MODEL |
+	                  (int)TreeLikelihoodGradientFlags::SITE_MODEL;
 	if (f & ~built)
-		throw Error("site-model and substitution-model gradients are not built yet (SURVEY.md 8f.1); request TREE_HEIGHT and/or BRANCH_MODEL");
+		throw Error("substitution-model gradients are not built yet (SURVEY.md 8f.1); request TREE_HEIGHT, SITE_MODEL and/or BRANCH_MODEL");
 	flags_ = f;
 	const phyamd::Tree &t = *treeModel_->GetTree();
 	size_t len = 0;
 	if (f & (int)TreeLikelihoodGradientFlags::TREE_HEIGHT) len += t.time_mode ? (size_t)t.tip_count - 1 : (size_t)t.node_count;
+	if (f & (int)TreeLikelihoodGradientFlags::SITE_MODEL)  // treelikelihood.c:279-287: shape, pinv, mu
+		len += (smc.dist != phyamd::RateDistribution::Constant) + (smc.has_pinv ? 1 : 0) + (smc.has_mu ? 1 : 0);
 	if ((f & (int)TreeLikelihoodGradientFlags::BRANCH_MODEL) && branchModel_) len += branchModel_->rates_.size();
 	gradientLength_ = len;
 	if (branchModel_ == nullptr) gradientLength_ -= 2;  // physher.cpp:639-641
@@ -516,14 +522,35 @@ void TreeLikelihoodInterface::Gradient(double *gradient) {
 	double lnl = 0.0;
 	const int eflags = referenceCompat_ ? (PHYAMD_GRAD_FOLD_ROOT_FREQS | PHYAMD_GRAD_COMPAT_SCALED) : 0;
 	phyamd::check(phyamd_gradient(I.engine, eflags, &lnl, I.cat_grad.data()));
-	// gradient_branch_length_from_cat_inplace (treelikelihood.c:3129-3143, 3258-3266)
+	if (!t.time_mode)  // treelikelihood.c:3249-3255: the right child of the root carries no branch of an unrooted tree
+		for (int c = 0; c < C; c++) I.cat_grad[(size_t)t.right[t.root] * C + c] = 0.0;
+	// site-model parameters: gradient_discrete_sitemodel (treelikelihood.c:3010-3052) on the per-category gradients
+	double site_grad[3];
+	size_t site_count = 0;
+	if (flags_ & (int)TreeLikelihoodGradientFlags::SITE_MODEL) {
+		std::vector<double> ingrad(C, 0.0);
+		const double mu = sm.has_mu ? sm.mu : 1.0;
+		for (int n = 0; n < N; n++) {
+			if (n == t.root || (!t.time_mode && n == t.right[t.root])) continue;
+			for (int c = sm.has_pinv ? 1 : 0; c < C; c++) ingrad[c] += I.cat_grad[(size_t)n * C + c] * I.branch_lengths[n] * mu;  // :3237-3242
+		}
+		if (sm.dist != phyamd::RateDistribution::Constant) site_grad[site_count++] = sm.shape_gradient(ingrad.data());
+		if (sm.has_pinv) {
+			phyamd::check(phyamd_root_invariant_term(I.engine, &ingrad[0]));
+			site_grad[site_count++] = sm.pinv_gradient(ingrad.data());
+		}
+	}
+	// gradient_branch_length_from_cat_inplace (treelikelihood.c:3129-3143, 3258-3266).  The reference weights by
+	// sm->cat_rates, i.e. WITHOUT mu, so its branch gradient is d lnL / d(mu * length); outside compatibility mode the
+	// missing factor mu is applied and the result is d lnL / d length.
 	std::vector<double> g(N, 0.0);
+	const double mu_factor = (sm.has_mu && !referenceCompat_) ? sm.mu : 1.0;
 	for (int n = 0; n < N; n++) {
-		if (C == 1) g[n] = I.cat_grad[n];
+		if (C == 1) g[n] = I.cat_grad[n] * mu_factor;
 		else {
 			double s = I.cat_grad[(size_t)n * C] * sm.cat_props[0] * sm.cat_rates[0];
 			for (int c = 1; c < C; c++) s += I.cat_grad[(size_t)n * C + c] * sm.cat_props[c] * sm.cat_rates[c];
-			g[n] = s;
+			g[n] = s * mu_factor;
 		}
 	}
 	size_t j = 0;
@@ -551,6 +578,15 @@ void TreeLikelihoodInterface::Gradient(double *gradient) {
 			} else
 				std::copy(gh.begin(), gh.end(), gradient);
 			j = (size_t)t.tip_count - 1;
+		}
+	}
+	if (flags_ & (int)TreeLikelihoodGradientFlags::SITE_MODEL) {
+		for (size_t i = 0; i < site_count; i++) gradient[j++] = site_grad[i];
+		if (sm.has_mu) {  // treelikelihood.c:3288-3302: sum over branches of d lnL / d(mu * length) times the length
+			double gm = 0.0;
+			for (int n = 0; n < N; n++)
+				if (n != t.root) gm += g[n] / mu_factor * I.branch_lengths[n];
+			gradient[j++] = gm;
 		}
 	}
 	if ((flags_ & (int)TreeLikelihoodGradientFlags::BRANCH_MODEL) && branchModel_) {

@@ -259,4 +259,43 @@ void SiteModel::update() {
 	dirty = false;
 }
 
+double SiteModel::quantile(double p, double a) const {
+	return dist == RateDistribution::Gamma ? gamma_quantile(p, a, a) : std::pow(-std::log(1.0 - p), 1.0 / a);
+}
+
+double SiteModel::shape_gradient(const double *ingrad) {
+	update();
+	const int inv = has_pinv ? 1 : 0, n = cat_count - inv;
+	std::vector<double> q(n), dq(n);
+	double sum = 0.0, dsum = 0.0;
+	for (int i = 0; i < n; i++) {
+		const double p = (2.0 * i + 1.0) / (2.0 * n);
+		q[i] = quantile(p, shape);
+		if (dist == RateDistribution::Gamma) {  // central difference in the shape, step cbrt(eps) * shape (sitemodel.c:266-289)
+			const double eps = std::cbrt(std::numeric_limits<double>::epsilon());
+			const double xp = shape * (1.0 + eps), xm = shape * (1.0 - eps);
+			dq[i] = (quantile(p, xp) - quantile(p, xm)) / (xp - xm);
+		} else
+			dq[i] = -q[i] * std::log(-std::log(1.0 - p)) / (shape * shape);  // sitemodel.c:386
+		sum += q[i] * cat_props[i + inv];
+		dsum += dq[i] * cat_props[i + inv];
+	}
+	double g = 0.0;
+	for (int i = 0; i < n; i++) g += ingrad[i + inv] * (dq[i] / sum - q[i] * dsum / sum / sum) * cat_props[i + inv];
+	return g;
+}
+
+double SiteModel::pinv_gradient(const double *ingrad) {
+	update();
+	if (dist == RateDistribution::Constant) return ingrad[0] + ingrad[1] / cat_props[1];  // +I only
+	const int n = cat_count - 1;
+	double sum = 0.0, g = 0.0;
+	for (int i = 0; i < n; i++) {
+		const double q = quantile((2.0 * i + 1.0) / (2.0 * n), shape);
+		sum += q;
+		g += ingrad[i + 1] * q;
+	}
+	return ingrad[0] + g / (sum * (1.0 - cat_props[0]));
+}
+
 }  // namespace phyamd

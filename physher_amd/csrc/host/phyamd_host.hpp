@@ -114,6 +114,11 @@ struct SiteModel {
 	bool dirty = true;
 	void update();
 	double rate(int c) { update(); return cat_rates[c] * (has_mu ? mu : 1.0); }
+	// ingrad[c] = sum over branches of cat_gradient[branch][c] * branch_length (x mu); for the +I term ingrad[0] is the
+	// root-partial sum of phyamd_root_invariant_term
+	double shape_gradient(const double *ingrad);  // _gamma_shape_derivative / _weibull_shape_derivative (sitemodel.c:258-308, 375-398)
+	double pinv_gradient(const double *ingrad);   // _gamma_inv_derivative / _weibull_inv_derivative (sitemodel.c:310-341, 400-426)
+	double quantile(double p, double shape_value) const;  // un-normalised class rate
 };
 double gamma_quantile(double p, double shape, double rate);  // lower-tail inverse CDF (gamma.c:55-58,194-228)
 double reg_lower_gamma(double a, double x);                  // P(a, x)

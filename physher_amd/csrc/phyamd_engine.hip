@@ -445,6 +445,31 @@ __global__ __launch_bounds__(64) void k_reduce_rows(const double *__restrict__ p
 	if (threadIdx.x == 0) out[row] = s;
 }
 
+// sum_k (w_k / L_k) sum_i pi_i ( p_root[0][k][i] - mean_{c >= 1} p_root[c][k][i] ): the d lnL / d(proportion of the
+// invariant class) term that needs the root partials (treelikelihood.c:2943-3008).  root: stored root partial;
+// cat_stride / pat_stride / state_stride describe its layout ([C][P][4] or planes [C][S][Pp]).
+__global__ __launch_bounds__(256) void k_root_invariant_term(int P, int S, int C, const double *__restrict__ root, size_t cat_stride, size_t pat_stride,
+                                                            size_t state_stride, const double *__restrict__ freqs,
+                                                            const double *__restrict__ w_over_L, double *__restrict__ part) {
+	__shared__ double red[4];
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	double acc = 0.0;
+	if (k < P) {
+		double s = 0.0;
+		for (int i = 0; i < S; i++) {
+			const double *p = root + (size_t)k * pat_stride + (size_t)i * state_stride;
+			double others = 0.0;
+			for (int c = 1; c < C; c++) others += p[(size_t)c * cat_stride];
+			s += freqs[i] * (p[0] - others / (C - 1));
+		}
+		acc = s * w_over_L[k];
+	}
+	const double t = wave_sum(acc);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+	__syncthreads();
+	if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void k_fill_nan(double *out, int n) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) out[i] = __longlong_as_double(0x7ff8000000000000LL);
@@ -466,6 +491,7 @@ struct phyamd_engine {
 	int Pp = 0;            // padded plane stride (generic)
 	int nblk_root = 0;     // workgroups of k_root_finish (generic)
 	double *d_Lc = nullptr;  // [C][P] per-category site likelihoods at the root (generic)
+	double *d_inv_part = nullptr;  // partial sums of k_root_invariant_term
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
@@ -1064,7 +1090,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc,
+	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})
@@ -1320,6 +1346,29 @@ int phyamd_branch_gradient(phyamd_engine *e, int flags, const double *rates_with
 		for (int c = 1; c < e->C; c++) g += cg[(size_t)n * e->C + c] * e->props[c] * r[c];
 		branch_gradient[n] = g;
 	}
+	return PHYAMD_OK;
+}
+
+int phyamd_root_invariant_term(phyamd_engine *e, double *out) {
+	CHECK_ENGINE(e);
+	if (!out) return fail(PHYAMD_EINVAL, "null out");
+	if (e->C < 2) return fail(PHYAMD_EINVAL, "the invariant-class term needs at least two categories");
+	if (e->scaling_on) return fail(PHYAMD_EUNSUPPORTED, "the invariant-class term is not built for rescaled evaluations");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	if ((rc = check_ready(e))) return rc;
+	const int nb = (e->P + 255) / 256;
+	if (!e->d_inv_part && (rc = dev_alloc(e, &e->d_inv_part, (size_t)nb + 1))) return rc;
+	const double *root = e->d_lower + (size_t)e->core_index[e->root] * node_partial_doubles(e);
+	const size_t cat_stride = e->generic ? (size_t)e->S * e->Pp : (size_t)e->P * e->S;
+	const size_t pat_stride = e->generic ? 1 : (size_t)e->S, state_stride = e->generic ? (size_t)e->Pp : 1;
+	hipLaunchKernelGGL(k_root_invariant_term, dim3(nb), dim3(256), 0, e->stream, e->P, e->S, e->C, root, cat_stride, pat_stride, state_stride, e->d_freqs,
+	                   e->d_wl, e->d_inv_part);
+	hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_inv_part, nb, (const uint8_t *)nullptr, e->d_inv_part + nb);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_inv_part + nb, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	*out = e->h_result[0];
 	return PHYAMD_OK;
 }
 

@@ -128,6 +128,11 @@ class Engine:
     def gradient_device(self, device_ptr, flags=0):
         self._check(self._lib.phyamd_gradient_device(self._h, flags, C.c_void_p(device_ptr)))
 
+    def root_invariant_term(self):
+        v = C.c_double()
+        self._check(self._lib.phyamd_root_invariant_term(self._h, C.byref(v)))
+        return v.value
+
     def synchronize(self):
         self._check(self._lib.phyamd_synchronize(self._h))
 

@@ -48,6 +48,15 @@ CASES = [
     ("wag_g4_t12_tipstates", dict(T=12, sites=80, seed=8, datatype="aa", model="wag", categories=4, alpha=0.5, tipstates=1)),
     # LG without explicit frequencies crashes in the reference (lg.c:47 builds a 0-dimensional simplex): pass them
     ("lg_g1_t9_gaps", dict(T=9, sites=60, seed=9, datatype="aa", model="lg", categories=1, gaps=0.05, freqs=AA_FREQS)),
+    # site-model gradient cases (shape, pinv, mu): SITE_MODEL block of gradient_all
+    ("gtr_g4i_mu_t14", dict(T=14, sites=400, seed=12, datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.6,
+                            pinv=0.15, mu=1.7)),
+    ("gtr_w3_t12", dict(T=12, sites=300, seed=13, datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=3, alpha=1.4,
+                        sitedist="weibull")),
+    ("hky_w4i_t10", dict(T=10, sites=300, seed=14, datatype="nucleotide", model="hky", rates="2.0", freqs="0.1,0.2,0.3,0.4", categories=4, alpha=0.9,
+                         sitedist="weibull", pinv=0.1)),
+    ("jc69_inv_t10", dict(T=10, sites=300, seed=15, datatype="nucleotide", model="jc69", freqs="0.25,0.25,0.25,0.25", categories=1,
+                          sitedist="discrete", pinv=0.2)),
     ("mg94_t8", dict(T=8, sites=40, seed=10, datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=1)),
     ("mg94_g2_t6_tipstates", dict(T=6, sites=30, seed=11, datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=2, alpha=0.8, tipstates=1)),
 ]
@@ -75,7 +84,7 @@ def run_case(name, o):
     with open(os.path.join(d, "tree.nwk"), "w") as f:
         f.write(tree.newick() + "\n")
     spec = [f"fasta {d}/aln.fa", f"newick {d}/tree.nwk", f"datatype {o['datatype']}", f"model {o['model']}"]
-    for k in ("rates", "freqs", "categories", "alpha", "tipstates", "sse", "rescale"):
+    for k in ("rates", "freqs", "categories", "alpha", "tipstates", "sse", "rescale", "sitedist", "pinv", "mu"):
         if k in o:
             spec.append(f"{k} {o[k]}")
     tmp_spec = os.path.join(d, "spec.abs.txt")

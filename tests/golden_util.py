@@ -43,7 +43,7 @@ def load(case):
     with gzip.open(os.path.join(GOLDEN, case, "expected.json.gz")) as f:
         exp = json.loads(f.read().decode())
     out = dict(exp)
-    for k in ("weights", "pattern_lk", "cat_rates", "cat_proportions", "frequencies", "eval", "gradient_tree", "gradient_all"):
+    for k in ("weights", "pattern_lk", "cat_rates", "cat_proportions", "cat_rates_without_mu", "frequencies", "eval", "gradient_tree", "gradient_all"):
         if k in exp:
             out[k] = np.array(exp[k], dtype=np.float64)
     S = exp["state_count"]

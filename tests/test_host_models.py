@@ -120,9 +120,12 @@ def test_gtr_simplex_and_general_model_agree():
 def test_gamma_rates_match_reference(case):
     gold = load(case)
     spec = read_spec(case)
-    sm = pc.GammaSiteModelInterface(float(spec["alpha"]), int(spec["categories"]))
-    np.testing.assert_allclose(sm.rates(), gold["cat_rates"], rtol=1e-10)
-    np.testing.assert_allclose(sm.proportions(), gold["cat_proportions"], rtol=0, atol=0)
+    pinv = float(spec["pinv"]) if "pinv" in spec else None
+    mu = float(spec["mu"]) if "mu" in spec else None
+    cls = pc.WeibullSiteModelInterface if spec.get("sitedist", "gamma") == "weibull" else pc.GammaSiteModelInterface
+    sm = cls(float(spec["alpha"]), int(spec["categories"]), pinv, mu)
+    np.testing.assert_allclose(sm.rates(), gold["cat_rates_without_mu"], rtol=1e-10, atol=1e-15)
+    np.testing.assert_allclose(sm.proportions(), gold["cat_proportions"], rtol=1e-15, atol=0)
 
 
 def test_site_model_variants():

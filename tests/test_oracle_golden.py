@@ -73,12 +73,18 @@ def test_log_likelihood(case):
     np.testing.assert_allclose(r["pattern_lk"], gold["pattern_lk"], rtol=1e-11, atol=1e-11)
     if "partials_root" in gold:
         T = gold["tip_count"]
-        np.testing.assert_allclose(r["lower"][gold["root"]], gold["partials_root"], rtol=1e-9, atol=1e-300)
-        np.testing.assert_allclose(r["lower"][T], gold["partials_first_internal"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(r["lower"][gold["root"]], gold["partials_root"], rtol=1e-9, atol=_atol(case))
+        np.testing.assert_allclose(r["lower"][T], gold["partials_first_internal"], rtol=1e-9, atol=_atol(case))
+
+
+def _atol(case):
+    # with an invariant class (rate 0) the reference's closed-form JC69/HKY matrices are exactly the identity while an
+    # eigen-system P(0) has 1e-17 off-diagonals: partial entries that are exactly 0 there are ~1e-17 here
+    return 1e-15 if "pinv" in read_spec(case) else 1e-300
 
 
 def _branch_gradient(gold, res):
-    return po.branch_gradient_from_cat(res["cat_grad"], gold["cat_rates"], gold["cat_proportions"],
+    return po.branch_gradient_from_cat(res["cat_grad"], gold["cat_rates_without_mu"], gold["cat_proportions"],
                                        zero_node=gold["right"][gold["root"]])
 
 
@@ -112,9 +118,9 @@ def test_branch_gradient(case, fold):
     assert np.abs(g[finite] - ref[finite]).max() <= 1e-9 * scale
     if fold and "upper_first_internal" in gold:
         T = gold["tip_count"]
-        np.testing.assert_allclose(r["upper"][T], gold["upper_first_internal"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(r["upper"][T], gold["upper_first_internal"], rtol=1e-9, atol=_atol(case))
         if spec["tipstates"] == "0":
-            np.testing.assert_allclose(r["upper"][0], gold["upper_tip0"], rtol=1e-9, atol=1e-300)
+            np.testing.assert_allclose(r["upper"][0], gold["upper_tip0"], rtol=1e-9, atol=_atol(case))
 
 
 def test_reference_folded_gradient_is_wrong_for_nonuniform_frequencies():

@@ -11,6 +11,7 @@ from golden_util import GOLDEN, UNROOTED_CASES, load, read_fasta, read_spec
 
 pytestmark = pytest.mark.gpu
 
+SITE_CASES = ["gtr_g4i_mu_t14", "gtr_w3_t12", "hky_w4i_t10", "jc69_inv_t10"]
 CASES4 = [c for c in UNROOTED_CASES if read_spec(c)["datatype"] == "nucleotide" and read_spec(c)["rescale"] == "0"
           and not load(c)["rescaled"]]
 
@@ -30,7 +31,17 @@ def _build(case, pc):
     else:
         subst = pc.GTRInterface([float(x) for x in spec["rates"].split(",")], f)
     C = int(spec["categories"])
-    site = pc.GammaSiteModelInterface(float(spec["alpha"]), C) if C > 1 else pc.ConstantSiteModelInterface()
+    pinv = float(spec["pinv"]) if "pinv" in spec else None
+    mu = float(spec["mu"]) if "mu" in spec else None
+    dist = spec.get("sitedist", "gamma")
+    if dist == "discrete":
+        site = pc.InvariantSiteModelInterface(pinv, mu)
+    elif C > 1 and dist == "weibull":
+        site = pc.WeibullSiteModelInterface(float(spec["alpha"]), C, pinv, mu)
+    elif C > 1:
+        site = pc.GammaSiteModelInterface(float(spec["alpha"]), C, pinv, mu)
+    else:
+        site = pc.ConstantSiteModelInterface(mu)
     tlk = pc.TreeLikelihoodInterface(list(zip(names, seqs)), tree, subst, site, None, use_tip_states=spec["tipstates"] == "1")
     return gold, tree, subst, site, tlk
 
@@ -44,6 +55,7 @@ def test_unrooted_likelihood_and_gradient(case):
     assert np.array_equal(tlk.pattern_states(), gold["patterns"]) and np.array_equal(tlk.pattern_weights(), gold["weights"])
     lnl = tlk.log_likelihood()
     assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+    tlk.request_gradient([pc.TreeLikelihoodGradientFlags.TREE_HEIGHT])
     assert tlk.gradient_length == N - 2  # physher.cpp:639-641
     # reference arithmetic (include_root_freqs = true): what physher returns for TREE_MODEL-only requests
     tlk.set_reference_compatibility(True)
@@ -54,8 +66,9 @@ def test_unrooted_likelihood_and_gradient(case):
     tlk.set_reference_compatibility(False)
     g = tlk.gradient()
     rr, rl = gold["right"][gold["root"]], gold["left"][gold["root"]]
+    mu = float(read_spec(case).get("mu", 1.0))
     if gold["gradient_all_flags"] & 4:
-        ref = gold["gradient_all"][: N - 2].copy()
+        ref = gold["gradient_all"][: N - 2].copy() * mu  # the reference's branch gradient leaves mu out (treelikelihood.c:3134)
         if rr < gold["tip_count"]:
             # bifurcating-root newick with a tip on the right: the root branch is parameter rr; the reference reports 0
             # for it (treelikelihood.c:3249-3255), the default mode reports its derivative = that of root->left
@@ -141,3 +154,43 @@ def test_fluA_reference_known_answers():
     assert abs(tlk.log_likelihood() - (-4786.867701371271)) > 1.0
     clock.set_rate(0.001)
     assert abs(tlk.log_likelihood() - (-4786.867701371271)) < 1e-8
+
+
+@pytest.mark.parametrize("case", SITE_CASES)
+def test_site_model_gradient(case):
+    """shape (Gamma: the reference's own central difference on the quantiles; Weibull: closed form), proportion of
+    invariant sites, mu -- the SITE_MODEL block of the reference's gradient (treelikelihood.c:3010-3052, 3277-3303)."""
+    from physher_amd import _phycpp_amd as pc
+    gold, tree, subst, site, tlk = _build(case, pc)
+    N = gold["node_count"]
+    np.testing.assert_allclose(site.rates(), gold["cat_rates_without_mu"], rtol=1e-10, atol=1e-15)
+    np.testing.assert_allclose(site.proportions(), gold["cat_proportions"], rtol=1e-14)
+    lnl = tlk.log_likelihood()
+    assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+    n_site = gold["site_rate_parameters"] + int(gold["site_has_pinv"]) + int(gold["site_has_mu"])
+    tlk.request_gradient([pc.TreeLikelihoodGradientFlags.TREE_HEIGHT, pc.TreeLikelihoodGradientFlags.SITE_MODEL])
+    assert tlk.gradient_length == N - 2 + n_site
+    g = tlk.gradient()
+    mu = float(read_spec(case).get("mu", 1.0))
+    ref_tree = gold["gradient_all"][: N - 2] * mu if gold["gradient_all_flags"] & 4 else None
+    if ref_tree is not None:
+        assert np.abs(g[: N - 2] - ref_tree).max() <= 1e-9 * max(1.0, np.abs(ref_tree).max())
+    ref_site = gold["gradient_all"][N: N + n_site]
+    if not (gold["gradient_all_flags"] & 4):
+        tlk.set_reference_compatibility(True)  # JC69: the reference ran with folded root frequencies (exact for uniform pi)
+        g = tlk.gradient()
+    np.testing.assert_allclose(g[N - 2:], ref_site, rtol=2e-7, atol=1e-7)
+    # and each is a derivative of lnL: central differences through the wrapper's SetParameters
+    p0 = site.get_parameters()
+    for i in range(n_site):
+        h = 1e-6 * max(1.0, abs(p0[i]))
+        pp, pm = p0.copy(), p0.copy()
+        pp[i] += h
+        pm[i] -= h
+        site.set_parameters(pp)
+        up = tlk.log_likelihood()
+        site.set_parameters(pm)
+        dn = tlk.log_likelihood()
+        fd = (up - dn) / (2 * h)
+        assert abs(fd - g[N - 2 + i]) <= 1e-4 * max(1.0, abs(fd)), (i, fd, g[N - 2 + i])
+    site.set_parameters(p0)
