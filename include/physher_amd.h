@@ -59,11 +59,12 @@ enum {
 typedef struct {
 	int32_t tip_count;      /* T */
 	int32_t pattern_count;  /* P (this engine's shard of the compressed patterns) */
-	int32_t state_count;    /* S: 4, 20, 61, ... */
+	int32_t state_count;    /* S: 4 (nucleotides), 20 (amino acids), 60 / 61 (codons); others -> PHYAMD_EUNSUPPORTED */
 	int32_t category_count; /* C */
 	int32_t device;         /* HIP device ordinal; -1 = current device */
-	int32_t rescale;        /* PHYAMD_RESCALE_* */
-	int64_t max_device_bytes; /* 0 = no cap; otherwise patterns are processed in tiles that fit */
+	int32_t rescale;        /* PHYAMD_RESCALE_* (rescaling kernels exist for S == 4; other S: NEVER or AUTO, which then never switches) */
+	int64_t max_device_bytes; /* 0 = no cap.  A cap below the engine's need makes phyamd_create fail with PHYAMD_ENOMEM
+	                             (processing the patterns in tiles that fit is not built yet: shard across engines instead) */
 	void *stream;           /* hipStream_t to run on, NULL = engine-owned stream */
 } phyamd_config;
 

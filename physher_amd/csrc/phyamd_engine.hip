@@ -470,10 +470,6 @@ __global__ __launch_bounds__(256) void k_root_invariant_term(int P, int S, int C
 	if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void k_fill_nan(double *out, int n) {
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = __longlong_as_double(0x7ff8000000000000LL);
-}
 
 #include "phyamd_general.inc"
 
