@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libphysher_amd.so")
+# PHYAMD_LIB: load another build of the same ABI (A/B experiments with kernel variants); default = the in-tree library
+LIB_PATH = os.environ.get("PHYAMD_LIB") or os.path.join(_HERE, "libphysher_amd.so")
 
 ABI_VERSION = 1
 

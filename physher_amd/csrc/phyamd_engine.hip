@@ -54,7 +54,18 @@ int fail(int code, const char *fmt, ...) {
 	} while (0)
 
 constexpr int WAVE = 64;             // lanes per wavefront (gfx950)
-constexpr int PPT = 4;               // pattern groups swept by one workgroup (sequentially, one barrier each)
+// tuning constants (A/B measured on MI355X at 1000 taxa x 1e6 patterns): pattern groups swept
+// sequentially by one workgroup, and the occupancy the pre-order kernel is compiled for
+#ifndef PHYAMD_PPT_LOWER
+#define PHYAMD_PPT_LOWER 2
+#endif
+#ifndef PHYAMD_PPT_UPPER
+#define PHYAMD_PPT_UPPER 8
+#endif
+#ifndef PHYAMD_UPPER_MIN_WAVES
+#define PHYAMD_UPPER_MIN_WAVES 6
+#endif
+constexpr int PPT_LOWER = PHYAMD_PPT_LOWER, PPT_UPPER = PHYAMD_PPT_UPPER;
 constexpr int MAX_WAVES = 16;        // 1024 threads
 constexpr double SCALING_THRESHOLD = 1.0e-40;  // treelikelihood.c:1121
 
@@ -162,6 +173,22 @@ __global__ void k_transition_matrices(int S, int C, int node_count, const double
 	}
 }
 
+// Tip messages, 4 states: for every (tip, category) the 16 vectors  P(t) . mask  (mask = 4-bit ambiguity code) are
+// tabulated once per evaluation, so "transition matrix times tip vector" is one 32-byte gather per (tip, pattern)
+// instead of 16 multiply-adds: tiptab[tip][c][mask][i] = sum_j P[i][j] bit_j(mask).  2 MB at 1000 taxa x 4 categories.
+__global__ void k_tip_tables(int T, int C, const double *__restrict__ mats, double *__restrict__ tiptab) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= T * C * 64) return;
+	const int i = idx & 3, m = (idx >> 2) & 15, tc = idx >> 6;  // tc = tip * C + c
+	const double *M = mats + (size_t)tc * 16 + i * 4;
+	double s = 0.0;
+	if (m & 1) s += M[0];
+	if (m & 2) s += M[1];
+	if (m & 4) s += M[2];
+	if (m & 8) s += M[3];
+	tiptab[idx] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 4-state kernels.  Workgroup = (64 lanes = patterns) x (C waves = categories) x (G pattern groups);
 // a wave's category is uniform, so its 4x4 matrices live in SGPRs and feed v_fma_f64 directly.
@@ -180,26 +207,33 @@ __global__ void k_transition_matrices(int S, int C, int node_count, const double
 struct Ctx4 {
 	const uint8_t *__restrict__ tipmask;
 	const double *__restrict__ mats;
+	const double *__restrict__ tiptab;
 	int P, C, c, k;
-	__device__ __forceinline__ d4 tip(int t) const { return mask4(tipmask[(size_t)t * P + k]); }
+	// P_t . tip vector: one gather from the per-(tip, category) table of the 16 possible masks
+	__device__ __forceinline__ d4 tipmsg(int t) const {
+		const unsigned m = tipmask[(size_t)t * P + k];
+		return load4(tiptab + (((size_t)t * C + c) * 16 + m) * 4);
+	}
 	__device__ __forceinline__ cptr M(int node) const { return opaque(as_const(mats + ((size_t)node * C + c) * 16)); }
 };
 
-// lower partial of one child at (pattern k, category c): tip mask, stored array, or a fringe subtree recomputed in registers
-__device__ __forceinline__ d4 child_value(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
-                                          const double *__restrict__ lower, size_t plane) {
-	if (kind == CH_TIP) return x.tip(node);
-	if (kind == CH_CORE) return load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4);
-	const d4 cherry = mul4(matvec4(x.M(t0), x.tip(t0)), matvec4(x.M(t1), x.tip(t1)));
-	if (kind == CH_CHERRY) return cherry;
-	return mul4(matvec4(x.M(inner), cherry), matvec4(x.M(t2), x.tip(t2)));  // CH_CHERRY_TIP
+// message of one child to its parent, P_child . p_child, at (pattern k, category c): a tip (table gather), a stored
+// array, or a fringe subtree recomputed in registers
+__device__ __forceinline__ d4 child_message(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
+                                            const double *__restrict__ lower, size_t plane) {
+	if (kind == CH_TIP) return x.tipmsg(node);
+	if (kind == CH_CORE) return matvec4(x.M(node), load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4));
+	const d4 cherry = mul4(x.tipmsg(t0), x.tipmsg(t1));
+	if (kind == CH_CHERRY) return matvec4(x.M(node), cherry);
+	return matvec4(x.M(node), mul4(matvec4(x.M(inner), cherry), x.tipmsg(t2)));  // CH_CHERRY_TIP
 }
 
 // dynamic LDS: 4 * G*C*64 doubles (two double-buffered exchanges) + G doubles (reduction)
 template <int WAVES, bool SCALE, bool ROOT>
 __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict__ ops, int T, int P, int C,
                                                         const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
-                                                        const double *__restrict__ mats, double *__restrict__ lscale,
+                                                        const double *__restrict__ mats, const double *__restrict__ tiptab,
+                                                        double *__restrict__ lscale,
                                                         const double *__restrict__ freqs, const double *__restrict__ props,
                                                         const double *__restrict__ weights, double *__restrict__ pattern_lk,
                                                         double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
@@ -213,14 +247,14 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict
 	double acc = 0.0;
 
 #pragma unroll 1
-	for (int q = 0; q < PPT; q++) {
-		const int k0 = ((blockIdx.x * PPT + q) * G + g) * WAVE + lane;
+	for (int q = 0; q < PPT_LOWER; q++) {
+		const int k0 = ((blockIdx.x * PPT_LOWER + q) * G + g) * WAVE + lane;
 		const bool valid = k0 < P;
-		const Ctx4 x{tipmask, mats, P, C, c, valid ? k0 : P - 1};
+		const Ctx4 x{tipmask, mats, tiptab, P, C, c, valid ? k0 : P - 1};
 		const int k = x.k;
-		const d4 a = child_value(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
-		const d4 b = child_value(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
-		d4 out = mul4(matvec4(x.M(op.left), a), matvec4(x.M(op.right), b));
+		const d4 a = child_message(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
+		const d4 b = child_message(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
+		d4 out = mul4(a, b);
 		double sf = 0.0;
 		if (SCALE) {  // SingleTreeLikelihood_scalePartials (treelikelihood.c:1790-1836): max over categories and states
 			double *xb = sh + (q & 1) * xsz;
@@ -302,11 +336,11 @@ struct Grad4 {
 // Ordered so that few vectors are live at once (the kernel is register-limited).
 __device__ __forceinline__ void descend_fringe(const Ctx4 &x, const Grad4 &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
                                                const d4 &u) {
-	const d4 b0 = matvec4(x.M(t0), x.tip(t0)), b1 = matvec4(x.M(t1), x.tip(t1));
+	const d4 b0 = x.tipmsg(t0), b1 = x.tipmsg(t1);
 	d4 a2 = matvec4(x.M(node), u);
 	if (kind == CH_CHERRY_TIP) {
 		const d4 bn = matvec4(x.M(inner), mul4(b0, b1));
-		const d4 b2 = matvec4(x.M(t2), x.tip(t2));
+		const d4 b2 = x.tipmsg(t2);
 		const d4 un = mul4(a2, b2);
 		gr.add(base + 2, un, bn);
 		gr.add(base + 3, mul4(a2, bn), b2);
@@ -317,10 +351,11 @@ __device__ __forceinline__ void descend_fringe(const Ctx4 &x, const Grad4 &gr, i
 }
 
 template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
-__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? 4 : 1) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
+__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 1) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
                                                         const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
                                                         double *__restrict__ upper, const double *__restrict__ mats,
-                                                        const double *__restrict__ Q, const double *__restrict__ freqs,
+                                                        const double *__restrict__ tiptab, const double *__restrict__ Q,
+                                                        const double *__restrict__ freqs,
                                                         const double *__restrict__ props, const double *__restrict__ weights,
                                                         const double *__restrict__ w_over_L, double *__restrict__ gpart, int nblk) {
 	extern __shared__ double sh[];
@@ -343,16 +378,14 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? 4 : 1) void k_upper4(cons
 	for (int i = 0; i < NACC; i++) gr.acc[i * WAVE] = 0.0;
 
 #pragma unroll 1
-	for (int q = 0; q < PPT; q++) {
-		const int k0 = ((blockIdx.x * PPT + q) * G + g) * WAVE + lane;
+	for (int q = 0; q < PPT_UPPER; q++) {
+		const int k0 = ((blockIdx.x * PPT_UPPER + q) * G + g) * WAVE + lane;
 		const bool valid = k0 < P;
-		const Ctx4 x{tipmask, mats, P, C, c, valid ? k0 : P - 1};
+		const Ctx4 x{tipmask, mats, tiptab, P, C, c, valid ? k0 : P - 1};
 		const int k = x.k;
-		const d4 vl = child_value(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
-		const d4 vr = child_value(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
+		const d4 bl = child_message(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
+		const d4 br = child_message(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
 		const d4 a = proot ? (FOLD ? pi : one) : matvec4(x.M(op.parent), load4(up + (size_t)k * 4));
-		const d4 bl = matvec4(x.M(op.left), vl);
-		const d4 br = matvec4(x.M(op.right), vr);
 		d4 ul = mul4(a, br), ur = mul4(a, bl);
 		if (!SCALE) {
 			// unscaled: divide by the site likelihood formed at the root, like the reference (treelikelihood.c:2879);
@@ -486,6 +519,7 @@ struct phyamd_engine {
 	bool generic = false;  // S != 4: MFMA kernels, plane layout [C][S][Pp]
 	int Pp = 0;            // padded plane stride (generic)
 	int nblk_root = 0;     // workgroups of k_root_finish (generic)
+	int nblk_lower = 0;    // pattern blocks of the post-order kernels
 	double *d_Lc = nullptr;  // [C][P] per-category site likelihoods at the root (generic)
 	double *d_inv_part = nullptr;  // partial sums of k_root_invariant_term
 	int device = 0;
@@ -519,6 +553,7 @@ struct phyamd_engine {
 	double *d_lower = nullptr, *d_upper = nullptr, *d_mats = nullptr, *d_dmats = nullptr;
 	double *d_Q = nullptr;
 	bool have_Q = false;
+	double *d_tiptab = nullptr;  // [T][C][16][4] tip messages (4-state)
 	double *d_model = nullptr, *d_freqs = nullptr, *d_rates = nullptr, *d_props = nullptr, *d_lengths = nullptr, *d_weights = nullptr;
 	double *d_wl = nullptr;  // [P] w_k / L_k from the root kernel (unscaled evaluations)
 	double *d_plk = nullptr, *d_lscale = nullptr, *d_lnl_part = nullptr, *d_gpart = nullptr, *d_result = nullptr;
@@ -762,6 +797,11 @@ int update_matrices(phyamd_engine *e) {
 		                   e->d_explicit, e->root, e->d_mats, e->d_dmats);
 		HIP_TRY(hipGetLastError());
 	}
+	if (!e->generic) {  // explicit matrices included: the tables are built from whatever d_mats holds
+		const int n = e->T * e->C * 64;
+		hipLaunchKernelGGL(k_tip_tables, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, e->C, e->d_mats, e->d_tiptab);
+		HIP_TRY(hipGetLastError());
+	}
 	e->matrices_dirty = false;
 	return PHYAMD_OK;
 }
@@ -777,15 +817,15 @@ int launch_lower_levels(phyamd_engine *e) {
 		const int off = e->lower_level_off[lv], cnt = e->lower_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		const bool is_root = lv == levels - 1;
-		dim3 grid(e->nblk, cnt);
+		dim3 grid(e->nblk_lower, cnt);
 		launched++;
 		if (is_root)
 			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, true>), grid, block_dims(e), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
+			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
 			                   e->d_lnl_part);
 		else
 			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, false>), grid, block_dims(e), SCALE ? lds : 0, e->stream, e->d_lower_ops + off, e->T, e->P,
-			                   e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
+			                   e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
 			                   e->d_lnl_part);
 	}
 	HIP_TRY(hipGetLastError());
@@ -810,7 +850,7 @@ int launch_upper_levels(phyamd_engine *e) {
 		dim3 grid(e->nblk, cnt);
 		launched++;
 		hipLaunchKernelGGL((k_upper4<WAVES, SCALE, FOLD, COMPAT>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C,
-		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_wl, e->d_gpart,
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_wl, e->d_gpart,
 		                   e->nblk);
 	}
 	HIP_TRY(hipGetLastError());
@@ -917,7 +957,7 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 	if (e->scaling_on && (rc = ensure_scaling_storage(e))) return rc;
 	for (int attempt = 0; attempt < 2; attempt++) {
 		if ((rc = launch_lower(e))) return rc;
-		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->generic ? e->nblk_root : e->nblk, (const uint8_t *)nullptr,
+		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->generic ? e->nblk_root : e->nblk_lower, (const uint8_t *)nullptr,
 		                   e->d_result);
 		HIP_TRY(hipGetLastError());
 		if (e->cfg.rescale != PHYAMD_RESCALE_AUTO || e->scaling_on || !need_host_check || e->generic) break;
@@ -1028,12 +1068,14 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 		return fail(PHYAMD_EUNSUPPORTED, "category_count %d exceeds %d (one wave per category)", cfg->category_count, MAX_WAVES);
 	}
 	e->G = std::max(1, 4 / e->C);  // at least 4 waves per workgroup
-	e->nblk = (e->P + WAVE * e->G * PPT - 1) / (WAVE * e->G * PPT);
+	e->nblk = (e->P + WAVE * e->G * PPT_UPPER - 1) / (WAVE * e->G * PPT_UPPER);        // pre-order kernel / gradient slabs
+	e->nblk_lower = (e->P + WAVE * e->G * PPT_LOWER - 1) / (WAVE * e->G * PPT_LOWER);  // post-order kernel / lnL slab
 	e->generic = e->S != 4;
 	if (e->generic) {
 		e->Pp = (e->P + 15) / 16 * 16;
 		const int ppb = e->S == 20 ? GenGeo<2>::PATTERNS_PER_BLOCK : GenGeo<4>::PATTERNS_PER_BLOCK;
 		e->nblk = (e->P + ppb - 1) / ppb;
+		e->nblk_lower = e->nblk;
 		e->nblk_root = (e->P + 255) / 256;
 	}
 	e->tip_set.assign(e->T, 0);
@@ -1053,6 +1095,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if ((rc = dev_alloc(e, &e->d_dmats, msz))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_model, (size_t)e->S + 2 * e->S * e->S))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_Q, (size_t)e->S * e->S))) return bail(rc);
+	if (!e->generic && (rc = dev_alloc(e, &e->d_tiptab, (size_t)e->T * e->C * 64))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_freqs, (size_t)e->S))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_rates, (size_t)e->C))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_props, (size_t)e->C))) return bail(rc);
@@ -1060,7 +1103,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if ((rc = dev_alloc(e, &e->d_weights, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_plk, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_wl, (size_t)e->P))) return bail(rc);
-	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)std::max(e->nblk, e->nblk_root)))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)std::max(std::max(e->nblk, e->nblk_lower), e->nblk_root)))) return bail(rc);
 	if (e->generic && (rc = dev_alloc(e, &e->d_Lc, (size_t)e->C * e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_gpart, (size_t)e->N * e->C * e->nblk))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_result, (size_t)1 + e->N * e->C))) return bail(rc);
@@ -1086,7 +1129,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part,
+	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})
