@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--cpu-sample-patterns", type=int, default=2000)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--subst-gradient", action="store_true",
+                    help="NOT the headline metric: each step also yields d lnL / d(5 GTR rates, 4 frequencies) (SURVEY 8f.1) in the same two passes")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run of this workload")
     args = ap.parse_args()
@@ -251,13 +253,24 @@ def main():
     eng.set_profiling(True)
 
     N = 2 * T - 1
-    result = torch.zeros(1 + N * C, dtype=torch.float64, device=device)
+    n_tail = 0
+    if args.subst_gradient:
+        if S != 4:
+            raise SystemExit("--subst-gradient: 4-state workloads only")
+        from physher_amd import _phycpp_amd as pc  # host model code: dQ/dtheta of GTR (5 rates relative to GT, then 4 frequencies)
+        dQ = pc.GTRInterface(list(GTR_RATES[:5]), list(GTR_FREQS)).rate_matrix_derivatives()
+        eng.set_rate_matrix_derivatives(dQ)
+        n_tail = len(dQ) + S
+    result = torch.zeros(1 + N * C + n_tail, dtype=torch.float64, device=device)
 
     def evaluate_shard(out):
         eng.set_branch_lengths(tree.length)  # invalidates every P(t): full recompute (benchmarking.c:498-500)
-        eng.gradient_device(out.data_ptr())  # HIP kernels on torch's current stream; [lnL, g[node][cat]] stays on the device
+        if args.subst_gradient:
+            eng.parameter_gradient_device(out.data_ptr())  # [lnL | g[node][cat] | 9 parameter sums | root frequency term]
+        else:
+            eng.gradient_device(out.data_ptr())  # HIP kernels on torch's current stream; [lnL, g[node][cat]] stays on the device
 
-    step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result, via_host=rehearsal)  # + one RCCL all-reduce + host epilogue
+    step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result, via_host=rehearsal, tail=n_tail)  # + one RCCL all-reduce + host epilogue
 
     def fence():
         torch.cuda.synchronize(device)
@@ -266,12 +279,12 @@ def main():
             torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
-        lnl, bg = step()
+        lnl, bg = step()[:2]
     fence()
     prof = dict(lower_ms=0.0, upper_ms=0.0, matrices_ms=0.0, reduce_ms=0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lnl, bg = step()
+        lnl, bg = step()[:2]
         p = eng.profile()  # HIP-event times of this evaluation, recorded on the engine's stream
         for k in prof:
             prof[k] += p[k]
@@ -302,7 +315,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "lnL+gradient evals/sec, 1000-taxon GTR+G4 fp64, 1e6 site patterns",
+            "metric": "lnL+gradient evals/sec, 1000-taxon GTR+G4 fp64, 1e6 site patterns"
+                      + (" [+ 9 substitution-parameter gradients per eval: NOT the headline metric]" if args.subst_gradient else ""),
             "value": value,
             "unit": "evals/s",
             "n_gpus": world,

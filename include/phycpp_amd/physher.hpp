@@ -277,5 +277,6 @@ class TreeLikelihoodInterface : public CallableModelInterface {
 	bool includeJacobian_;
 	bool referenceCompat_ = false;
 	int flags_ = 0;
+	bool substRates_ = false, substFreqs_ = false;
 	std::unique_ptr<phyamd::LikelihoodImpl> impl_;
 };

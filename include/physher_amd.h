@@ -122,6 +122,27 @@ int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out);
  * of the +I site-model gradient that needs O(P) data (gradient_pinv_sitemodel / gradient_pinv_W_sitemodel,
  * treelikelihood.c:2943-3008); the rest of that gradient is O(N C) host arithmetic on phyamd_gradient's output. */
 int phyamd_root_invariant_term(phyamd_engine *e, double *out);
+
+/* --- substitution-model gradient (4-state models): calculate_dlnl_dQ (treelikelihood.c:2337-2583) --- */
+#define PHYAMD_MAX_PARAMETERS 64
+/* dQ [count][S][S]: derivative of the (normalised) rate matrix with respect to each parameter, what the reference's
+ * m->dQ holds after _gtr_dQdp / _hky_dQdp / _general_dQdp (gtr.c:256-326, hky.c:493-541, gensubst.c:216-279).  The engine
+ * forms dP/dtheta = U ((U^-1 dQ U) o F(t)) U^-1 per branch and category itself (dPdp_with_dQdp, substmodel.c:469-489).
+ * Needs phyamd_set_eigen; count = 0 clears. */
+int phyamd_set_rate_matrix_derivatives(phyamd_engine *e, int count, const double *dQ);
+/* One post-order + one pre-order pass giving lnL, the per-category branch gradient (cat_gradient may be NULL) and
+ *   parameter_gradient[th] = sum_k (w_k / L_k) sum_branches sum_c w_c sum_i pi_i u_i (dP_th p)_i
+ * i.e. the branch sum of calculate_dlnl_dQ for all parameters at once (the reference re-walks the tree per parameter).
+ * For a frequency parameter add dpi_f/dtheta * phyamd_root_frequency_term()[f] (treelikelihood.c:2370-2401).
+ * Works with rescaling; PHYAMD_GRAD_FOLD_ROOT_FREQS is refused (the reference clears include_root_freqs here). */
+int phyamd_parameter_gradient(phyamd_engine *e, int flags, double *lnl, double *cat_gradient, double *parameter_gradient);
+/* Device-resident form for multi-GPU sharding, like phyamd_gradient_device: writes
+ * [lnL | g[node][cat] | parameter_gradient[count] | root frequency term[S]]  (1 + (2T-1)*C + count + S doubles, all of them
+ * sums over this engine's patterns) to `device_out` on the engine's stream, no host synchronisation. */
+int phyamd_parameter_gradient_device(phyamd_engine *e, int flags, double *device_out);
+/* After an evaluation: out[f] = sum_k w_k (sum_c w_c p_root[c][k][f]) / (sum_i pi_i sum_c w_c p_root[c][k][i]), f < S:
+ * d lnL / d pi_f through the root frequencies alone. */
+int phyamd_root_frequency_term(phyamd_engine *e, double *out /* [S] */);
 int phyamd_synchronize(phyamd_engine *e);
 
 /* --- inspection (parity tests, debugging) --- */

@@ -158,3 +158,54 @@ def branch_gradient_from_cat(cat_grad, cat_rates, cat_props, zero_node=None):
     for j in range(1, g.shape[1]):
         out = out + g[:, j] * cat_props[j] * cat_rates[j]
     return out
+
+
+def parameter_matrix(eval_, evec, ivec, dQ, t):
+    """dP/dtheta at time t from dQ/dtheta: dPdp_with_dQdp (substmodel.c:469-489)."""
+    lam = np.asarray(eval_, dtype=np.float64)
+    e = np.exp(lam * t)
+    B = np.asarray(ivec) @ np.asarray(dQ) @ np.asarray(evec)
+    S = len(lam)
+    F = np.empty((S, S))
+    for i in range(S):
+        for j in range(S):
+            F[i, j] = (e[i] - e[j]) / (lam[i] - lam[j]) if lam[i] != lam[j] else t * e[i]
+    return np.asarray(evec) @ (B * F) @ np.asarray(ivec)
+
+
+def parameter_gradient(problem: "Problem", dQ, skip_nodes=()):
+    """Branch part of calculate_dlnl_dQ (treelikelihood.c:2402-2583, include_root_freqs = false) for every dQ/dtheta
+    in dQ [count][S][S]:  sum_k w_k  [sum_branches sum_c w_c sum_i pi_i u_i (dP p)_i] / L_k.  Under rescaling the
+    reference forms each branch's ratio in that branch's scaled units (:2545-2556); unscaled it divides by the
+    root site likelihood (:2573-2577).  Returns (lnL, gradient [count])."""
+    r = problem.gradient(want_partials=True)
+    lower, upper = r["lower"], r["upper"]  # [N][C][P][S]
+    dQ = np.asarray(dQ, dtype=np.float64).reshape(-1, problem.S, problem.S)
+    out = np.zeros(len(dQ))
+    pi, w, props = problem.freqs, problem.weights, problem.cat_props
+    L = np.exp(r["pattern_lk"])
+    for th, d in enumerate(dQ):
+        acc = np.zeros(problem.P)
+        for n in range(problem.N):
+            if n == problem.root or n in skip_nodes:
+                continue
+            num = np.zeros(problem.P)
+            den = np.zeros(problem.P)
+            for c in range(problem.C):
+                t = problem.branch_lengths[n] * problem.cat_rates[c]
+                dP = parameter_matrix(problem.eval, problem.evec, problem.ivec, d, t)
+                num += props[c] * np.einsum("i,ki,ij,kj->k", pi, upper[n, c], dP, lower[n, c])
+                if r["rescaled"]:
+                    Pm = np.abs(p_t(problem.S, problem.eval, problem.evec, problem.ivec, t))
+                    den += props[c] * np.einsum("i,ki,ij,kj->k", pi, upper[n, c], Pm, lower[n, c])
+            acc += num / den if r["rescaled"] else num / L
+        out[th] = np.sum(acc * w)
+    return r["lnl"], out
+
+
+def root_frequency_term(problem: "Problem"):
+    """d lnL / d pi_f through the root frequencies alone (treelikelihood.c:2370-2401): [S]."""
+    r = problem.log_likelihood(want_lower=True)
+    root = np.einsum("c,cks->ks", problem.cat_props, r["lower"][problem.root])
+    like = root @ problem.freqs
+    return (problem.weights / like) @ root

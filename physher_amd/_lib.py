@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PHYAMD_LIB: load another build of the same ABI (A/B experiments with kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("PHYAMD_LIB") or os.path.join(_HERE, "libphysher_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, EINVAL, EDEVICE, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
 RESCALE_NEVER, RESCALE_ALWAYS, RESCALE_AUTO = 0, 1, 2
@@ -57,6 +57,10 @@ SYMBOLS = [
     ("phyamd_branch_gradient", C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), _P]),
     ("phyamd_gradient_device", C.c_int, [_P, C.c_int, _P]),
     ("phyamd_root_invariant_term", C.c_int, [_P, C.POINTER(C.c_double)]),
+    ("phyamd_set_rate_matrix_derivatives", C.c_int, [_P, C.c_int, _P]),
+    ("phyamd_parameter_gradient", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), _P, _P]),
+    ("phyamd_parameter_gradient_device", C.c_int, [_P, C.c_int, _P]),
+    ("phyamd_root_frequency_term", C.c_int, [_P, _P]),
     ("phyamd_synchronize", C.c_int, [_P]),
     ("phyamd_get_pattern_log_likelihoods", C.c_int, [_P, _P]),
     ("phyamd_get_partials", C.c_int, [_P, C.c_int, C.c_int, _P]),

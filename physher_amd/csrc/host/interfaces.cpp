@@ -375,6 +375,8 @@ struct LikelihoodImpl {
 	phyamd_engine *engine = nullptr;
 	Patterns patterns;
 	unsigned long tree_v = ~0ul, subst_v = ~0ul, site_v = ~0ul, clock_v = ~0ul;
+	unsigned long dq_v = ~0ul;  // substitution-model version the uploaded dQ/dtheta belong to
+	bool dq_rates = false, dq_freqs = false;
 	std::vector<double> branch_lengths, cat_grad;
 	~LikelihoodImpl() {
 		if (engine) phyamd_destroy(engine);
@@ -446,24 +448,35 @@ void TreeLikelihoodInterface::RequestGradient(std::vector<TreeLikelihoodGradient
 	for (auto x : flags) f |= (int)x;
 	const phyamd::SiteModel &smc = *siteModel_->GetModel();
 	const bool site_params = smc.dist != phyamd::RateDistribution::Constant || smc.has_pinv || smc.has_mu;
-	if (f == 0) {  // TreeLikelihood_initialize_gradient(flags = 0): whatever this build can differentiate (treelikelihood.c:255-270)
+	const phyamd::SubstModel &mc = *substitutionModel_->GetModel();
+	const bool subst_params = mc.S == 4 && mc.name != "JC69";  // m->dPdp != NULL (gtr.c:102, hky.c:72, gensubst.c:189); device side: 4 states
+	if (f == 0) {  // TreeLikelihood_initialize_gradient(flags = 0): everything differentiable (treelikelihood.c:255-270)
 		f = (int)TreeLikelihoodGradientFlags::TREE_HEIGHT;
 		if (site_params) f |= (int)TreeLikelihoodGradientFlags::SITE_MODEL;
 		if (branchModel_) f |= (int)TreeLikelihoodGradientFlags::BRANCH_MODEL;
+		if (subst_params) f |= (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL;
 	}
-	const int built = (int)TreeLikelihoodGradientFlags::TREE_HEIGHT | (int)TreeLikelihoodGradientFlags::BRANCH_MODEL |
-	                  (int)TreeLikelihoodGradientFlags::SITE_MODEL;
-	if (f & ~built)
-		throw Error("substitution-model gradients are not built yet (SURVEY.md 8f.1); request TREE_HEIGHT, SITE_MODEL and/or BRANCH_MODEL");
+	const int subst_flags = (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL | (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL_RATES |
+	                        (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL_FREQUENCIES;
+	if ((f & subst_flags) && !subst_params)
+		throw Error(mc.S != 4 ? "substitution-model gradients are built for 4-state models only"
+		                      : "this substitution model has no differentiable parameters (no dPdp in the reference either)");
 	flags_ = f;
+	// treelikelihood.c:247-249: SUBSTITUTION_MODEL = rates + frequencies
+	substRates_ = f & ((int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL | (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL_RATES);
+	substFreqs_ = f & ((int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL | (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL_FREQUENCIES);
 	const phyamd::Tree &t = *treeModel_->GetTree();
 	size_t len = 0;
 	if (f & (int)TreeLikelihoodGradientFlags::TREE_HEIGHT) len += t.time_mode ? (size_t)t.tip_count - 1 : (size_t)t.node_count;
 	if (f & (int)TreeLikelihoodGradientFlags::SITE_MODEL)  // treelikelihood.c:279-287: shape, pinv, mu
 		len += (smc.dist != phyamd::RateDistribution::Constant) + (smc.has_pinv ? 1 : 0) + (smc.has_mu ? 1 : 0);
 	if ((f & (int)TreeLikelihoodGradientFlags::BRANCH_MODEL) && branchModel_) len += branchModel_->rates_.size();
+	if (substRates_) len += (size_t)mc.rate_parameter_count();  // treelikelihood.c:296-305: constrained values, K of a simplex
+	if (substFreqs_) len += (size_t)mc.S;
 	gradientLength_ = len;
-	if (branchModel_ == nullptr) gradientLength_ -= 2;  // physher.cpp:639-641
+	// physher.cpp:639-641 drops the two root-adjacent entries of the unrooted tree block; the reference subtracts them even
+	// when no tree block was requested (and then mis-copies in Gradient, physher.cpp:648-655) -- here only with a tree block
+	if (branchModel_ == nullptr && (f & (int)TreeLikelihoodGradientFlags::TREE_HEIGHT)) gradientLength_ -= 2;
 }
 
 void TreeLikelihoodInterface::Sync() {
@@ -520,8 +533,29 @@ void TreeLikelihoodInterface::Gradient(double *gradient) {
 	const int N = t.node_count, C = sm.cat_count;
 	I.cat_grad.assign((size_t)N * C, 0.0);
 	double lnl = 0.0;
-	const int eflags = referenceCompat_ ? (PHYAMD_GRAD_FOLD_ROOT_FREQS | PHYAMD_GRAD_COMPAT_SCALED) : 0;
-	phyamd::check(phyamd_gradient(I.engine, eflags, &lnl, I.cat_grad.data()));
+	const bool subst = substRates_ || substFreqs_;
+	// a substitution-model request clears include_root_freqs in the reference too (treelikelihood.c:291-305)
+	const int eflags = referenceCompat_ ? ((subst ? 0 : PHYAMD_GRAD_FOLD_ROOT_FREQS) | PHYAMD_GRAD_COMPAT_SCALED) : 0;
+	std::vector<double> subst_grad;
+	if (subst) {  // gradient_PMatrix (treelikelihood.c:3077-3110): all parameters in the same two passes as the branch gradient
+		phyamd::SubstModel &m = *substitutionModel_->GetModel();
+		if (I.dq_v != substitutionModel_->version_ || I.dq_rates != substRates_ || I.dq_freqs != substFreqs_) {
+			std::vector<double> dQ;
+			m.rate_matrix_derivatives(substRates_, substFreqs_, dQ);
+			phyamd::check(phyamd_set_rate_matrix_derivatives(I.engine, (int)(dQ.size() / ((size_t)m.S * m.S)), dQ.data()));
+			I.dq_v = substitutionModel_->version_;
+			I.dq_rates = substRates_;
+			I.dq_freqs = substFreqs_;
+		}
+		subst_grad.resize((substRates_ ? m.rate_parameter_count() : 0) + (substFreqs_ ? m.S : 0));
+		phyamd::check(phyamd_parameter_gradient(I.engine, eflags, &lnl, I.cat_grad.data(), subst_grad.data()));
+		if (substFreqs_) {  // + the root term d lnL / d pi_f (treelikelihood.c:2370-2401)
+			std::vector<double> rootf(m.S);
+			phyamd::check(phyamd_root_frequency_term(I.engine, rootf.data()));
+			for (int f = 0; f < m.S; f++) subst_grad[subst_grad.size() - m.S + f] += rootf[f];
+		}
+	} else
+		phyamd::check(phyamd_gradient(I.engine, eflags, &lnl, I.cat_grad.data()));
 	if (!t.time_mode)  // treelikelihood.c:3249-3255: the right child of the root carries no branch of an unrooted tree
 		for (int c = 0; c < C; c++) I.cat_grad[(size_t)t.right[t.root] * C + c] = 0.0;
 	// site-model parameters: gradient_discrete_sitemodel (treelikelihood.c:3010-3052) on the per-category gradients
@@ -596,6 +630,7 @@ void TreeLikelihoodInterface::Gradient(double *gradient) {
 			if (n != t.root) gc[branchModel_->map_[n]] += g[n] * (t.height[t.parent[n]] - t.height[n]);
 		for (double v : gc) gradient[j++] = v;
 	}
+	for (double v : subst_grad) gradient[j++] = v;  // [rates][frequencies], treelikelihood.c:3313-3357
 	if (std::isnan(lnl) || std::isinf(lnl))
 		for (size_t i = 0; i < j; i++) gradient[i] = NAN;  // treelikelihood.c:327-332
 }

@@ -107,8 +107,9 @@ void SubstModel::update() {
 			}
 		Q[(size_t)i * S + i] = -row;  // make_zero_rows
 	}
+	norm = 1.0;
 	if (normalize) {  // normalize_Q (substmodel.c:1135-1143): one expected substitution per unit time
-		double norm = 0.0;
+		norm = 0.0;
 		for (int i = 0; i < S; i++) norm -= Q[(size_t)i * S + i] * freqs[i];
 		for (double &q : Q) q /= norm;
 	}
@@ -131,6 +132,54 @@ void SubstModel::update() {
 			ivec[(size_t)k * S + i] = V[(size_t)i * S + k] * d[i];
 		}
 	dirty = false;
+}
+
+void SubstModel::rate_matrix_derivatives(bool want_rates, bool want_freqs, std::vector<double> &dQ) {
+	update();
+	dQ.clear();
+	if (name == "JC69") return;  // no dPdp in the reference (jc69.c): nothing to differentiate
+	std::vector<double> R;
+	build_symmetric_rates(*this, R);
+	std::vector<double> dR((size_t)S * S), dF(S), dq((size_t)S * S);
+	// one parameter: exchangeability perturbation dR (symmetric) and frequency perturbation dF
+	auto emit = [&]() {
+		double dnorm = 0.0;
+		for (int i = 0; i < S; i++) {
+			double row = 0.0;
+			for (int j = 0; j < S; j++)
+				if (i != j) {
+					dq[(size_t)i * S + j] = dR[(size_t)i * S + j] * freqs[j] + R[(size_t)i * S + j] * dF[j];  // build_Q_flat (substmodel.c:450-466)
+					row += dq[(size_t)i * S + j];
+				}
+			dq[(size_t)i * S + i] = -row;
+			// d norm = -sum_i ( dQ^_ii pi_i + Q^_ii dpi_i ), Q^_ii = Q_ii norm  (gtr.c:314-316)
+			dnorm -= dq[(size_t)i * S + i] * freqs[i] + Q[(size_t)i * S + i] * norm * dF[i];
+		}
+		for (size_t a = 0; a < dq.size(); a++) dQ.push_back(normalize ? (dq[a] - Q[a] * dnorm) / norm : dq[a]);  // gtr.c:319-324
+	};
+	if (want_rates) {
+		std::fill(dF.begin(), dF.end(), 0.0);
+		const std::vector<double> saved = rates;
+		for (size_t r = 0; r < saved.size(); r++) {
+			// R is linear in every rate: dR/dr = R(e_r) - R(0), with the constants (GTR's GT = 1, HKY's transversions) cancelling
+			std::vector<double> R1, R0;
+			std::fill(rates.begin(), rates.end(), 0.0);
+			build_symmetric_rates(*this, R0);
+			rates[r] = 1.0;
+			build_symmetric_rates(*this, R1);
+			for (size_t a = 0; a < dR.size(); a++) dR[a] = R1[a] - R0[a];
+			rates = saved;
+			emit();
+		}
+	}
+	if (want_freqs) {
+		std::fill(dR.begin(), dR.end(), 0.0);
+		for (int f = 0; f < S; f++) {
+			std::fill(dF.begin(), dF.end(), 0.0);
+			dF[f] = 1.0;
+			emit();
+		}
+	}
 }
 
 void SubstModel::p_t(double t, double *P, bool derivative) {

@@ -92,9 +92,16 @@ struct SubstModel {
 	bool normalize = true;
 	// derived
 	std::vector<double> Q, eval, evec, ivec;  // row-major
+	double norm = 1.0;                        // normalising constant the unnormalised Q was divided by (1 if !normalize)
 	bool dirty = true;
 	void update();                                // build Q (normalised, rows sum to 0) and its eigen system
 	void p_t(double t, double *P, bool derivative = false);  // host reference of M1/M2, used by tests
+	// Differentiable parameters in the reference's order and its constrained-value convention (grad_wrt_reparam = false,
+	// treelikelihood.c:296-305): the rates as stored, then every frequency as a free coordinate.
+	int rate_parameter_count() const { return name == "JC69" ? 0 : (int)rates.size(); }
+	// d(normalised Q)/d(parameter), [count][S][S]: _gtr_dQdp / _hky_dQdp / _general_dQdp (gtr.c:256-326, hky.c:493-541,
+	// gensubst.c:216-279) in one rule: dQ^ = dR o pi + R o dpi (rows re-zeroed), dQ = (dQ^ - Q dnorm) / norm
+	void rate_matrix_derivatives(bool want_rates, bool want_freqs, std::vector<double> &dQ);
 };
 void build_symmetric_rates(const SubstModel &m, std::vector<double> &R);  // exchangeabilities r_ij (i < j), row-major full matrix
 

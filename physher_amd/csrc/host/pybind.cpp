@@ -120,6 +120,14 @@ PYBIND11_MODULE(_phycpp_amd, m) {
 		         return darray({sm.S, sm.S}, P.data());
 	         },
 	         py::arg("t"), py::arg("derivative") = false)
+	    .def("rate_matrix_derivatives",  // dQ/dtheta [count][S][S] as uploaded for the substitution-model gradient
+	         [](SubstitutionModelInterface &self, bool rates, bool frequencies) {
+		         phyamd::SubstModel &sm = *self.GetModel();
+		         std::vector<double> dQ;
+		         sm.rate_matrix_derivatives(rates, frequencies, dQ);
+		         return darray({(py::ssize_t)(dQ.size() / ((size_t)sm.S * sm.S)), (py::ssize_t)sm.S, (py::ssize_t)sm.S}, dQ.data());
+	         },
+	         py::arg("rates") = true, py::arg("frequencies") = true)
 	    .def("eigen_system", [](SubstitutionModelInterface &self) {
 		    phyamd::SubstModel &sm = *self.GetModel();
 		    sm.update();

@@ -29,7 +29,7 @@
 
 #include "physher_amd.h"
 
-#define PHYAMD_ABI_VERSION 1
+#define PHYAMD_ABI_VERSION 2
 
 namespace {
 
@@ -189,6 +189,52 @@ __global__ void k_tip_tables(int T, int C, const double *__restrict__ mats, doub
 	tiptab[idx] = s;
 }
 
+// G2: dP/dtheta for every (parameter, node, category) from B_theta = U^-1 (dQ/dtheta) U:
+//   dP = U ( B o F(t) ) U^-1,  F_ab = (e^{l_a t} - e^{l_b t}) / (l_a - l_b)  or  t e^{l_a t} when l_a == l_b
+// (dPdp_with_dQdp, substmodel.c:469-489).  dpm: [NP][N][C][S][S]; root and explicit-matrix nodes get zeros.
+__global__ void k_parameter_matrices(int S, int C, int node_count, int np, const double *__restrict__ model, const double *__restrict__ B,
+                                     const double *__restrict__ rates, const double *__restrict__ lengths,
+                                     const uint8_t *__restrict__ is_explicit, int root, double *__restrict__ dpm) {
+	const size_t per = (size_t)node_count * C * S * S, total = per * np;
+	const double *eval = model, *evec = model + S, *ivec = model + S + S * S;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		const int j = idx % S;
+		const int i = (idx / S) % S;
+		const int c = (idx / ((size_t)S * S)) % C;
+		const int n = (idx / ((size_t)S * S * C)) % node_count;
+		const int th = idx / per;
+		double v = 0.0;
+		if (n != root && !is_explicit[n]) {
+			const double t = lengths[n] * rates[c];
+			const double *Bt = B + (size_t)th * S * S;
+			for (int a = 0; a < S; a++) {
+				const double ea = exp(eval[a] * t);
+				double row = 0.0;
+				for (int b = 0; b < S; b++) {
+					const double f = eval[a] != eval[b] ? (ea - exp(eval[b] * t)) / (eval[a] - eval[b]) : t * ea;
+					row += Bt[a * S + b] * f * ivec[b * S + j];
+				}
+				v += evec[i * S + a] * row;
+			}
+		}
+		dpm[idx] = v;
+	}
+}
+
+// tip tables of dP/dtheta, like k_tip_tables: dptab[th][tip][c][mask][i] = sum_j dP_th[tip][c][i][j] bit_j(mask)
+__global__ void k_parameter_tip_tables(int T, int N, int C, int np, const double *__restrict__ dpm, double *__restrict__ dptab) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= np * T * C * 64) return;
+	const int i = idx & 3, m = (idx >> 2) & 15, tc = (idx >> 6) % (T * C), th = (idx >> 6) / (T * C);
+	const double *M = dpm + ((size_t)th * N * C + tc) * 16 + i * 4;
+	double s = 0.0;
+	if (m & 1) s += M[0];
+	if (m & 2) s += M[1];
+	if (m & 4) s += M[2];
+	if (m & 8) s += M[3];
+	dptab[idx] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 4-state kernels.  Workgroup = (64 lanes = patterns) x (C waves = categories) x (G pattern groups);
 // a wave's category is uniform, so its 4x4 matrices live in SGPRs and feed v_fma_f64 directly.
@@ -226,6 +272,17 @@ __device__ __forceinline__ d4 child_message(const Ctx4 &x, int kind, int node, i
 	const d4 cherry = mul4(x.tipmsg(t0), x.tipmsg(t1));
 	if (kind == CH_CHERRY) return matvec4(x.M(node), cherry);
 	return matvec4(x.M(node), mul4(matvec4(x.M(inner), cherry), x.tipmsg(t2)));  // CH_CHERRY_TIP
+}
+// same, also handing back p_child itself, which the substitution-parameter gradient contracts with dP/dtheta
+__device__ __forceinline__ d4 child_message_pre(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
+                                                const double *__restrict__ lower, size_t plane, d4 &pre) {
+	if (kind == CH_TIP) return x.tipmsg(node);
+	if (kind == CH_CORE) pre = load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4);
+	else {
+		pre = mul4(x.tipmsg(t0), x.tipmsg(t1));                                            // cherry
+		if (kind == CH_CHERRY_TIP) pre = mul4(matvec4(x.M(inner), pre), x.tipmsg(t2));    // cherry + tip
+	}
+	return matvec4(x.M(node), pre);
 }
 
 // dynamic LDS: 4 * G*C*64 doubles (two double-buffered exchanges) + G doubles (reduction)
@@ -323,10 +380,29 @@ struct Grad4 {
 	cptr Q;
 	d4 f;
 	double wl;
-	double *acc;  // this thread's NACC accumulators in LDS: acc[i * WAVE] (lane-interleaved, conflict-free)
+	double *acc;  // this thread's accumulators in LDS: acc[i * WAVE] (lane-interleaved, conflict-free)
+	// substitution-parameter side (PARAMS kernels only): dP/dtheta per (parameter, node, category) and their tip tables
+	const double *__restrict__ dpm;    // [NP][N][C][16]
+	const double *__restrict__ dptab;  // [NP][T][C][16][4]
+	int np, N, T;
+	double wc;                         // category proportion: parameter terms are summed over categories
 	// acc[i] += w_k / L_k * sum_i f_i u_i (Q b)_i
 	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const {
 		acc[i * WAVE] += wl * dot4(mul4(f, u), matvec4(opaque(Q), b));
+	}
+	// acc[NACC + th] += w_c w_k / L_k sum_i f_i u_i (dP_th,node p)_i   (calculate_dlnl_dQ, treelikelihood.c:2472-2580)
+	__device__ __forceinline__ void addp_vec(const Ctx4 &x, int node, const d4 &u, const d4 &p) const {
+		const d4 fu = mul4(f, u);
+		for (int th = 0; th < np; th++) {
+			const cptr D = opaque(as_const(dpm + (((size_t)th * N + node) * x.C + x.c) * 16));
+			acc[(NACC + th) * WAVE] += wc * wl * dot4(fu, matvec4(D, p));
+		}
+	}
+	__device__ __forceinline__ void addp_tip(const Ctx4 &x, int tip, const d4 &u) const {
+		const d4 fu = mul4(f, u);
+		const unsigned m = x.tipmask[(size_t)tip * x.P + x.k];
+		for (int th = 0; th < np; th++)
+			acc[(NACC + th) * WAVE] += wc * wl * dot4(fu, load4(dptab + ((((size_t)th * T + tip) * x.C + x.c) * 16 + m) * 4));
 	}
 };
 
@@ -334,36 +410,49 @@ struct Grad4 {
 //   CH_CHERRY     : +0 -> t0, +1 -> t1
 //   CH_CHERRY_TIP : +0 -> t0, +1 -> t1 (inside the inner cherry), +2 -> inner, +3 -> t2
 // Ordered so that few vectors are live at once (the kernel is register-limited).
+template <bool PARAMS>
 __device__ __forceinline__ void descend_fringe(const Ctx4 &x, const Grad4 &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
                                                const d4 &u) {
 	const d4 b0 = x.tipmsg(t0), b1 = x.tipmsg(t1);
 	d4 a2 = matvec4(x.M(node), u);
 	if (kind == CH_CHERRY_TIP) {
-		const d4 bn = matvec4(x.M(inner), mul4(b0, b1));
+		const d4 pn = mul4(b0, b1);
+		const d4 bn = matvec4(x.M(inner), pn);
 		const d4 b2 = x.tipmsg(t2);
 		const d4 un = mul4(a2, b2);
 		gr.add(base + 2, un, bn);
 		gr.add(base + 3, mul4(a2, bn), b2);
+		if (PARAMS) {
+			gr.addp_vec(x, inner, un, pn);
+			gr.addp_tip(x, t2, mul4(a2, bn));
+		}
 		a2 = matvec4(x.M(inner), un);  // now the upper message entering the inner cherry
 	}
 	gr.add(base + 0, mul4(a2, b1), b0);
 	gr.add(base + 1, mul4(a2, b0), b1);
+	if (PARAMS) {
+		gr.addp_tip(x, t0, mul4(a2, b1));
+		gr.addp_tip(x, t1, mul4(a2, b0));
+	}
 }
 
-template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
-__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 1) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
+template <int WAVES, bool SCALE, bool FOLD, bool COMPAT, bool PARAMS>
+__global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER_MIN_WAVES : 1) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
                                                         const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
                                                         double *__restrict__ upper, const double *__restrict__ mats,
                                                         const double *__restrict__ tiptab, const double *__restrict__ Q,
                                                         const double *__restrict__ freqs,
                                                         const double *__restrict__ props, const double *__restrict__ weights,
-                                                        const double *__restrict__ w_over_L, double *__restrict__ gpart, int nblk) {
+                                                        const double *__restrict__ w_over_L, double *__restrict__ gpart, int nblk,
+                                                        const double *__restrict__ dpm, const double *__restrict__ dptab, int np, int N,
+                                                        double *__restrict__ ppart, int op_base, int op_total) {
 	extern __shared__ double sh[];
 	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const NodeOp op = ops[blockIdx.y];
 	const size_t plane = (size_t)P * 4;
 	const bool proot = op.upper_slot_parent < 0;
+	const int nacc = NACC + (PARAMS ? np : 0);  // accumulator columns per thread
 	const double *up = proot ? nullptr : upper + ((size_t)op.upper_slot_parent * C + c) * plane;
 	double *ul_dst = op.upper_slot_left < 0 ? nullptr : upper + ((size_t)op.upper_slot_left * C + c) * plane;
 	double *ur_dst = op.upper_slot_right < 0 ? nullptr : upper + ((size_t)op.upper_slot_right * C + c) * plane;
@@ -373,9 +462,8 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 
 	// gradient accumulators live in LDS (one column per thread), not in registers: the kernel is VGPR-limited
 	const int wv = g * C + c, nw = G * C;
 	double *red = sh + (SCALE ? 6 * xsz : 0);
-	Grad4 gr{as_const(Q), FOLD ? one : pi, 0.0, red + (size_t)wv * NACC * WAVE + lane};
-#pragma unroll
-	for (int i = 0; i < NACC; i++) gr.acc[i * WAVE] = 0.0;
+	Grad4 gr{as_const(Q), FOLD ? one : pi, 0.0, red + (size_t)wv * nacc * WAVE + lane, dpm, dptab, np, N, T, props[c]};
+	for (int i = 0; i < nacc; i++) gr.acc[i * WAVE] = 0.0;
 
 #pragma unroll 1
 	for (int q = 0; q < PPT_UPPER; q++) {
@@ -383,8 +471,11 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 
 		const bool valid = k0 < P;
 		const Ctx4 x{tipmask, mats, tiptab, P, C, c, valid ? k0 : P - 1};
 		const int k = x.k;
-		const d4 bl = child_message(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
-		const d4 br = child_message(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
+		d4 prel = one, prer = one;  // the children's own partials (PARAMS only)
+		const d4 bl = PARAMS ? child_message_pre(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane, prel)
+		                     : child_message(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
+		const d4 br = PARAMS ? child_message_pre(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane, prer)
+		                     : child_message(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
 		const d4 a = proot ? (FOLD ? pi : one) : matvec4(x.M(op.parent), load4(up + (size_t)k * 4));
 		d4 ul = mul4(a, br), ur = mul4(a, bl);
 		if (!SCALE) {
@@ -395,8 +486,14 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 
 			gr.add(1, ur, br);
 			if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
 			if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
-			if (op.kind_left >= CH_CHERRY) descend_fringe(x, gr, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
-			if (op.kind_right >= CH_CHERRY) descend_fringe(x, gr, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
+			if (PARAMS) {
+				if (op.kind_left == CH_TIP) gr.addp_tip(x, op.left, ul);
+				else gr.addp_vec(x, op.left, ul, prel);
+				if (op.kind_right == CH_TIP) gr.addp_tip(x, op.right, ur);
+				else gr.addp_vec(x, op.right, ur, prer);
+			}
+			if (op.kind_left >= CH_CHERRY) descend_fringe<PARAMS>(x, gr, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
+			if (op.kind_right >= CH_CHERRY) descend_fringe<PARAMS>(x, gr, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
 			continue;
 		} else {
 			// rescaled (always an unfused schedule): L_k underflows by construction, so the mixture likelihood is re-formed
@@ -420,6 +517,13 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 
 			const double w = valid ? weights[k] : 0.0, d = COMPAT ? den : D;
 			gr.acc[0] += w * (numl / d);
 			gr.acc[WAVE] += w * (numr / d);
+			if (PARAMS) {  // mixture numerator over the mixture likelihood in this branch's units (treelikelihood.c:2545-2556)
+				gr.wl = w / D;
+				if (op.kind_left == CH_TIP) gr.addp_tip(x, op.left, ul);
+				else gr.addp_vec(x, op.left, ul, prel);
+				if (op.kind_right == CH_TIP) gr.addp_tip(x, op.right, ur);
+				else gr.addp_vec(x, op.right, ur, prer);
+			}
 			// uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
 			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
 			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
@@ -430,8 +534,8 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 
 	// Fixed-order reduction over the workgroup's patterns: the accumulators sit in LDS as [wave][acc][lane];
 	// one lane per (wave, accumulator) adds the 64 entries in lane order; wave 0 of each category adds the pattern groups.
 	__syncthreads();
-	if (lane < NACC) {
-		const double *src = red + ((size_t)wv * NACC + lane) * WAVE;
+	if (lane < nacc) {
+		const double *src = red + ((size_t)wv * nacc + lane) * WAVE;
 		double s0 = src[0], s1 = src[16], s2 = src[32], s3 = src[48];  // four chains of 16, then a fixed combine
 		for (int j = 1; j < 16; j++) {
 			s0 += src[j];
@@ -440,13 +544,13 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 
 			s3 += src[48 + j];
 		}
 		const double s = (s0 + s1) + (s2 + s3);
-		red[(size_t)nw * NACC * WAVE + wv * NACC + lane] = s;
+		red[(size_t)nw * nacc * WAVE + wv * nacc + lane] = s;
 	}
 	__syncthreads();
+	const double *tot = red + (size_t)nw * nacc * WAVE;
 	if (g == 0 && lane < NACC) {
-		const double *tot = red + (size_t)nw * NACC * WAVE;
-		double s = tot[c * NACC + lane];
-		for (int gg = 1; gg < G; gg++) s += tot[(gg * C + c) * NACC + lane];
+		double s = tot[c * nacc + lane];
+		for (int gg = 1; gg < G; gg++) s += tot[(gg * C + c) * nacc + lane];
 		// accumulator -> gradient row (node id); -1 = unused for this op
 		const int kl = op.kind_left, kr = op.kind_right;
 		int node = -1;
@@ -463,6 +567,11 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_UPPER_MIN_WAVES : 
 			case 9: node = kr == CH_CHERRY_TIP ? op.rt2 : -1; break;
 		}
 		if (node >= 0) gpart[((size_t)node * C + c) * nblk + blockIdx.x] = s;
+	}
+	if (PARAMS && wv == 0 && lane < np) {  // parameter terms: sum over all waves (categories and pattern groups) in a fixed order
+		double s = 0.0;
+		for (int w = 0; w < nw; w++) s += tot[w * nacc + NACC + lane];
+		ppart[((size_t)lane * op_total + op_base + blockIdx.y) * nblk + blockIdx.x] = s;
 	}
 }
 
@@ -503,6 +612,36 @@ __global__ __launch_bounds__(256) void k_root_invariant_term(int P, int S, int C
 	if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The root term of d lnL / d pi_f (calculate_dlnl_dQ, treelikelihood.c:2370-2401): for every state f
+//   sum_k w_k  ( sum_c w_c p_root[c][k][f] )  /  ( sum_i pi_i sum_c w_c p_root[c][k][i] ).
+// Scale factors are per pattern, so the same expression serves rescaled evaluations.  part: [S][gridDim.x]
+__global__ __launch_bounds__(256) void k_root_frequency_term(int P, int S, int C, const double *__restrict__ root, size_t cat_stride, size_t pat_stride,
+                                                            size_t state_stride, const double *__restrict__ freqs, const double *__restrict__ props,
+                                                            const double *__restrict__ weights, double *__restrict__ part) {
+	__shared__ double red[4];
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	double like = 0.0;
+	if (k < P)
+		for (int i = 0; i < S; i++) {
+			const double *p = root + (size_t)k * pat_stride + (size_t)i * state_stride;
+			double m = 0.0;
+			for (int c = 0; c < C; c++) m += props[c] * p[(size_t)c * cat_stride];
+			like += freqs[i] * m;
+		}
+	const double wl = k < P ? weights[k] / like : 0.0;
+	for (int f = 0; f < S; f++) {
+		double m = 0.0;
+		if (k < P) {
+			const double *p = root + (size_t)k * pat_stride + (size_t)f * state_stride;
+			for (int c = 0; c < C; c++) m += props[c] * p[(size_t)c * cat_stride];
+		}
+		const double t = wave_sum(m * wl);
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+		__syncthreads();
+		if (threadIdx.x == 0) part[(size_t)f * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+	}
+}
 
 #include "phyamd_general.inc"
 
@@ -554,6 +693,16 @@ struct phyamd_engine {
 	double *d_Q = nullptr;
 	bool have_Q = false;
 	double *d_tiptab = nullptr;  // [T][C][16][4] tip messages (4-state)
+	// substitution-parameter gradient (G2)
+	int np = 0;                      // number of dQ/dtheta matrices set
+	std::vector<double> dQ_host;     // [np][S][S]
+	double *d_B = nullptr;           // [np][S][S]  U^-1 dQ U
+	double *d_dpm = nullptr;         // [np][N][C][S][S]
+	double *d_dptab = nullptr;       // [np][T][C][16][4]
+	double *d_ppart = nullptr;       // [np][upper ops][nblk] per-workgroup parameter sums, then [np][upper ops]
+	double *d_rf_part = nullptr;     // [S][blocks] partial sums of k_root_frequency_term, then [S]
+	size_t np_alloc = 0, ppart_alloc = 0;
+	bool params_dirty = true;
 	double *d_model = nullptr, *d_freqs = nullptr, *d_rates = nullptr, *d_props = nullptr, *d_lengths = nullptr, *d_weights = nullptr;
 	double *d_wl = nullptr;  // [P] w_k / L_k from the root kernel (unscaled evaluations)
 	double *d_plk = nullptr, *d_lscale = nullptr, *d_lnl_part = nullptr, *d_gpart = nullptr, *d_result = nullptr;
@@ -838,20 +987,33 @@ int launch_lower_w(phyamd_engine *e) {
 	return e->scaling_on ? launch_lower_levels<WAVES, true>(e) : launch_lower_levels<WAVES, false>(e);
 }
 
-template <int WAVES, bool SCALE, bool FOLD, bool COMPAT>
-int launch_upper_levels(phyamd_engine *e) {
+template <typename K>
+int allow_big_lds(K kernel, size_t bytes) {
+	if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	return PHYAMD_OK;
+}
+
+// one pre-order pass.  PARAMS: also accumulate the substitution-parameter sums of parameters [p0, p0 + pc)
+template <int WAVES, bool SCALE, bool FOLD, bool COMPAT, bool PARAMS>
+int launch_upper_levels(phyamd_engine *e, int p0 = 0, int pc = 0) {
 	const int levels = (int)e->upper_level_off.size() - 1;
 	int launched = 0;
-	const size_t nw = (size_t)e->G * e->C;
-	const size_t lds = sizeof(double) * ((SCALE ? 6 * nw * WAVE : 0) + nw * NACC * WAVE + nw * NACC);
+	const size_t nw = (size_t)e->G * e->C, nacc = NACC + (PARAMS ? pc : 0);
+	const size_t lds = sizeof(double) * ((SCALE ? 6 * nw * WAVE : 0) + nw * nacc * WAVE + nw * nacc);
+	int rc;
+	if ((rc = allow_big_lds(k_upper4<WAVES, SCALE, FOLD, COMPAT, PARAMS>, lds))) return rc;
+	const int op_total = (int)e->upper_ops.size();
+	const double *dpm = PARAMS ? e->d_dpm + (size_t)p0 * e->N * e->C * 16 : nullptr;
+	const double *dptab = PARAMS ? e->d_dptab + (size_t)p0 * e->T * e->C * 64 : nullptr;
+	double *ppart = PARAMS ? e->d_ppart + (size_t)p0 * op_total * e->nblk : nullptr;
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		dim3 grid(e->nblk, cnt);
 		launched++;
-		hipLaunchKernelGGL((k_upper4<WAVES, SCALE, FOLD, COMPAT>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C,
+		hipLaunchKernelGGL((k_upper4<WAVES, SCALE, FOLD, COMPAT, PARAMS>), grid, block_dims(e), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->C,
 		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_props, e->d_weights, e->d_wl, e->d_gpart,
-		                   e->nblk);
+		                   e->nblk, dpm, dptab, pc, e->N, ppart, off, op_total);
 	}
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = launched;
@@ -862,19 +1024,37 @@ template <int WAVES>
 int launch_upper_w(phyamd_engine *e, int flags) {
 	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS, compat = (flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on;
 	if (e->scaling_on) {
-		if (fold) return compat ? launch_upper_levels<WAVES, true, true, true>(e) : launch_upper_levels<WAVES, true, true, false>(e);
-		return compat ? launch_upper_levels<WAVES, true, false, true>(e) : launch_upper_levels<WAVES, true, false, false>(e);
+		if (fold) return compat ? launch_upper_levels<WAVES, true, true, true, false>(e) : launch_upper_levels<WAVES, true, true, false, false>(e);
+		return compat ? launch_upper_levels<WAVES, true, false, true, false>(e) : launch_upper_levels<WAVES, true, false, false, false>(e);
 	}
-	return fold ? launch_upper_levels<WAVES, false, true, false>(e) : launch_upper_levels<WAVES, false, false, false>(e);
+	return fold ? launch_upper_levels<WAVES, false, true, false, false>(e) : launch_upper_levels<WAVES, false, false, false, false>(e);
+}
+
+// largest number of parameter accumulators one workgroup's LDS holds next to the NACC branch accumulators
+int parameter_chunk(const phyamd_engine *e) {
+	const size_t nw = (size_t)e->G * e->C, budget = 160 * 1024 / sizeof(double) - (e->scaling_on ? 6 * nw * WAVE : 0);
+	const long cols = (long)(budget / (nw * (WAVE + 1))) - NACC;
+	return (int)std::max(0L, std::min(32L, cols));
+}
+
+template <int WAVES>
+int launch_upper_params_w(phyamd_engine *e, int flags) {
+	const bool compat = (flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on;
+	const int chunk = parameter_chunk(e);
+	if (chunk < 1) return fail(PHYAMD_EUNSUPPORTED, "%d categories leave no LDS for parameter accumulators", e->C);
+	int rc = PHYAMD_OK;
+	// more parameters than one workgroup can accumulate: repeat the pass (uppers and branch sums are rewritten with identical values)
+	for (int p0 = 0; p0 < e->np && !rc; p0 += chunk) {
+		const int pc = std::min(chunk, e->np - p0);
+		if (e->scaling_on)
+			rc = compat ? launch_upper_levels<WAVES, true, false, true, true>(e, p0, pc) : launch_upper_levels<WAVES, true, false, false, true>(e, p0, pc);
+		else
+			rc = launch_upper_levels<WAVES, false, false, false, true>(e, p0, pc);
+	}
+	return rc;
 }
 
 // ---- S != 4: MFMA kernels -----------------------------------------------------------------------------------
-template <typename K>
-int allow_big_lds(K kernel, size_t bytes) {
-	if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-	return PHYAMD_OK;
-}
-
 template <int RT, int KT>
 int launch_lower_gen(phyamd_engine *e) {
 	const int levels = (int)e->lower_level_off.size() - 1;
@@ -933,6 +1113,11 @@ int launch_upper(phyamd_engine *e, int flags) {
 	return waves <= 4 ? launch_upper_w<4>(e, flags) : waves <= 8 ? launch_upper_w<8>(e, flags) : launch_upper_w<16>(e, flags);
 }
 
+int launch_upper_params(phyamd_engine *e, int flags) {
+	const int waves = e->C * e->G;
+	return waves <= 4 ? launch_upper_params_w<4>(e, flags) : waves <= 8 ? launch_upper_params_w<8>(e, flags) : launch_upper_params_w<16>(e, flags);
+}
+
 int rebuild_schedule(phyamd_engine *e) {
 	int rc;
 	if ((rc = build_schedule(e))) return rc;
@@ -976,14 +1161,99 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 	return PHYAMD_OK;
 }
 
-int run_gradient(phyamd_engine *e, int flags) {
+// B_theta = U^-1 dQ_theta U, dP/dtheta matrices and their tip tables (recomputed per call: O(np N C) work)
+int update_parameter_matrices(phyamd_engine *e) {
+	const int S = e->S, np = e->np;
 	int rc;
+	if ((size_t)np > e->np_alloc) {
+		dev_free(e, &e->d_B, e->np_alloc * S * S);
+		dev_free(e, &e->d_dpm, e->np_alloc * e->N * e->C * S * S);
+		dev_free(e, &e->d_dptab, e->np_alloc * e->T * e->C * 64);
+		e->np_alloc = 0;
+		if ((rc = dev_alloc(e, &e->d_B, (size_t)np * S * S)) || (rc = dev_alloc(e, &e->d_dpm, (size_t)np * e->N * e->C * S * S)) ||
+		    (rc = dev_alloc(e, &e->d_dptab, (size_t)np * e->T * e->C * 64)))
+			return rc;
+		e->np_alloc = np;
+	}
+	const size_t need = (size_t)np * e->upper_ops.size() * ((size_t)e->nblk + 1);
+	if (need > e->ppart_alloc) {
+		dev_free(e, &e->d_ppart, e->ppart_alloc);
+		e->ppart_alloc = 0;
+		if ((rc = dev_alloc(e, &e->d_ppart, need))) return rc;
+		e->ppart_alloc = need;
+	}
+	if (e->params_dirty) {
+		const double *evec = e->model.data() + S, *ivec = e->model.data() + S + S * S;
+		std::vector<double> B((size_t)np * S * S), tmp((size_t)S * S);
+		for (int th = 0; th < np; th++) {
+			const double *dQ = e->dQ_host.data() + (size_t)th * S * S;
+			for (int a = 0; a < S; a++)
+				for (int j = 0; j < S; j++) {
+					double v = 0.0;
+					for (int i = 0; i < S; i++) v += ivec[a * S + i] * dQ[i * S + j];
+					tmp[a * S + j] = v;
+				}
+			for (int a = 0; a < S; a++)
+				for (int b = 0; b < S; b++) {
+					double v = 0.0;
+					for (int j = 0; j < S; j++) v += tmp[a * S + j] * evec[j * S + b];
+					B[((size_t)th * S + a) * S + b] = v;
+				}
+		}
+		HIP_TRY(hipMemcpyAsync(e->d_B, B.data(), sizeof(double) * B.size(), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));  // B is a stack-lifetime buffer
+		e->params_dirty = false;
+	}
+	const size_t total = (size_t)np * e->N * e->C * S * S;
+	hipLaunchKernelGGL(k_parameter_matrices, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, e->stream, S, e->C, e->N, np, e->d_model,
+	                   e->d_B, e->d_rates, e->d_lengths, e->d_explicit, e->root, e->d_dpm);
+	const int n = np * e->T * e->C * 64;
+	hipLaunchKernelGGL(k_parameter_tip_tables, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, e->N, e->C, np, e->d_dpm, e->d_dptab);
+	HIP_TRY(hipGetLastError());
+	return PHYAMD_OK;
+}
+
+// d lnL / d pi_f through the root frequencies, f < S, written to dst (device) on the engine's stream
+int launch_root_frequency_term(phyamd_engine *e, double *dst) {
+	int rc;
+	const int nb = (e->P + 255) / 256;
+	if (!e->d_rf_part && (rc = dev_alloc(e, &e->d_rf_part, ((size_t)nb + 1) * e->S))) return rc;
+	const double *root = e->d_lower + (size_t)e->core_index[e->root] * node_partial_doubles(e);
+	const size_t cat_stride = e->generic ? (size_t)e->S * e->Pp : (size_t)e->P * e->S;
+	const size_t pat_stride = e->generic ? 1 : (size_t)e->S, state_stride = e->generic ? (size_t)e->Pp : 1;
+	hipLaunchKernelGGL(k_root_frequency_term, dim3(nb), dim3(256), 0, e->stream, e->P, e->S, e->C, root, cat_stride, pat_stride, state_stride, e->d_freqs,
+	                   e->d_props, e->d_weights, e->d_rf_part);
+	hipLaunchKernelGGL(k_reduce_rows, dim3(e->S), dim3(64), 0, e->stream, e->d_rf_part, nb, (const uint8_t *)nullptr, dst ? dst : e->d_rf_part + (size_t)nb * e->S);
+	HIP_TRY(hipGetLastError());
+	return PHYAMD_OK;
+}
+
+int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
+	int rc;
+	if (with_params) {
+		if (e->generic) return fail(PHYAMD_EUNSUPPORTED, "substitution-parameter gradients are built for 4-state models only");
+		if (e->np < 1) return fail(PHYAMD_EINVAL, "phyamd_set_rate_matrix_derivatives has not been called");
+		if (!e->have_eigen) return fail(PHYAMD_EINVAL, "substitution-parameter gradients need the eigen system (phyamd_set_eigen)");
+		if (flags & PHYAMD_GRAD_FOLD_ROOT_FREQS)
+			return fail(PHYAMD_EINVAL, "PHYAMD_GRAD_FOLD_ROOT_FREQS cannot be combined with parameter gradients (the reference clears include_root_freqs, treelikelihood.c:291-305)");
+	}
 	if ((rc = run_lower(e, true))) return rc;
 	if ((rc = ensure_upper_storage(e))) return rc;
 	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
-	if ((rc = launch_upper(e, flags))) return rc;
+	if (with_params) {
+		if ((rc = update_parameter_matrices(e))) return rc;
+		if ((rc = launch_upper_params(e, flags))) return rc;
+	} else if ((rc = launch_upper(e, flags)))
+		return rc;
 	record(e, 3);
 	hipLaunchKernelGGL(k_reduce_rows, dim3(e->N * e->C), dim3(64), 0, e->stream, e->d_gpart, e->nblk, e->d_row_valid, e->d_result + 1);
+	if (with_params) {  // [np][ops][nblk] -> [np][ops] -> [np], fixed order
+		const int ops = (int)e->upper_ops.size();
+		double *stage = e->d_ppart + (size_t)e->np * ops * e->nblk;
+		hipLaunchKernelGGL(k_reduce_rows, dim3(e->np * ops), dim3(64), 0, e->stream, e->d_ppart, e->nblk, (const uint8_t *)nullptr, stage);
+		hipLaunchKernelGGL(k_reduce_rows, dim3(e->np), dim3(64), 0, e->stream, stage, ops, (const uint8_t *)nullptr, e->d_result + 1 + (size_t)e->N * e->C);
+		if ((rc = launch_root_frequency_term(e, e->d_result + 1 + (size_t)e->N * e->C + e->np))) return rc;
+	}
 	HIP_TRY(hipGetLastError());
 	record(e, 4);
 	e->prof_with_upper = true;
@@ -1106,11 +1376,11 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)std::max(std::max(e->nblk, e->nblk_lower), e->nblk_root)))) return bail(rc);
 	if (e->generic && (rc = dev_alloc(e, &e->d_Lc, (size_t)e->C * e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_gpart, (size_t)e->N * e->C * e->nblk))) return bail(rc);
-	if ((rc = dev_alloc(e, &e->d_result, (size_t)1 + e->N * e->C))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_result, (size_t)1 + e->N * e->C + 2 * PHYAMD_MAX_PARAMETERS))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_explicit, (size_t)e->N))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_row_valid, (size_t)e->N * e->C))) return bail(rc);
 	{
-		hipError_t err = hipHostMalloc(reinterpret_cast<void **>(&e->h_result), sizeof(double) * ((size_t)1 + e->N * e->C), hipHostMallocDefault);
+		hipError_t err = hipHostMalloc(reinterpret_cast<void **>(&e->h_result), sizeof(double) * ((size_t)1 + e->N * e->C + 2 * PHYAMD_MAX_PARAMETERS), hipHostMallocDefault);
 		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "hipHostMalloc: %s", hipGetErrorString(err)));
 		err = hipMemsetAsync(e->d_explicit, 0, e->N, e->stream);
 		if (err == hipSuccess) err = hipMemsetAsync(e->d_gpart, 0, sizeof(double) * (size_t)e->N * e->C * e->nblk, e->stream);
@@ -1129,7 +1399,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})
@@ -1276,6 +1546,7 @@ int phyamd_set_eigen(phyamd_engine *e, const double *eval, const double *evec, c
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_eigen = true;
 	e->matrices_dirty = true;
+	e->params_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1385,6 +1656,57 @@ int phyamd_branch_gradient(phyamd_engine *e, int flags, const double *rates_with
 		for (int c = 1; c < e->C; c++) g += cg[(size_t)n * e->C + c] * e->props[c] * r[c];
 		branch_gradient[n] = g;
 	}
+	return PHYAMD_OK;
+}
+
+int phyamd_set_rate_matrix_derivatives(phyamd_engine *e, int count, const double *dQ) {
+	CHECK_ENGINE(e);
+	if (count < 0 || count > PHYAMD_MAX_PARAMETERS) return fail(PHYAMD_EINVAL, "count %d outside 0..%d", count, PHYAMD_MAX_PARAMETERS);
+	if (count > 0 && !dQ) return fail(PHYAMD_EINVAL, "null dQ");
+	if (count > 0 && e->generic) return fail(PHYAMD_EUNSUPPORTED, "substitution-parameter gradients are built for 4-state models only");
+	e->np = count;
+	e->dQ_host.assign(dQ, dQ + (size_t)count * e->S * e->S);
+	e->params_dirty = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_parameter_gradient(phyamd_engine *e, int flags, double *lnl, double *cat_gradient, double *parameter_gradient) {
+	CHECK_ENGINE(e);
+	if (!parameter_gradient) return fail(PHYAMD_EINVAL, "null parameter_gradient");
+	int rc;
+	if ((rc = run_gradient(e, flags, true))) return rc;
+	const size_t ncat = (size_t)e->N * e->C, n = 1 + ncat + e->np;
+	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	finish_profile(e, true);
+	const double l = e->h_result[0];
+	if (lnl) *lnl = l;
+	const bool bad = std::isnan(l) || std::isinf(l);  // treelikelihood.c:327-332
+	for (size_t i = 0; cat_gradient && i < ncat; i++) cat_gradient[i] = bad ? NAN : e->h_result[1 + i];
+	for (int i = 0; i < e->np; i++) parameter_gradient[i] = bad ? NAN : e->h_result[1 + ncat + i];
+	return PHYAMD_OK;
+}
+
+int phyamd_parameter_gradient_device(phyamd_engine *e, int flags, double *device_out) {
+	CHECK_ENGINE(e);
+	if (!device_out) return fail(PHYAMD_EINVAL, "null device_out");
+	int rc;
+	if ((rc = run_gradient(e, flags, true))) return rc;
+	HIP_TRY(hipMemcpyAsync(device_out, e->d_result, sizeof(double) * ((size_t)1 + e->N * e->C + e->np + e->S), hipMemcpyDeviceToDevice, e->stream));
+	return PHYAMD_OK;
+}
+
+int phyamd_root_frequency_term(phyamd_engine *e, double *out) {
+	CHECK_ENGINE(e);
+	if (!out) return fail(PHYAMD_EINVAL, "null out");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	if ((rc = check_ready(e))) return rc;
+	if (e->core_index.empty() || e->core_index[e->root] < 0 || !e->d_lower) return fail(PHYAMD_EINVAL, "no evaluation has been run yet");
+	if ((rc = launch_root_frequency_term(e, nullptr))) return rc;
+	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_rf_part + (size_t)((e->P + 255) / 256) * e->S, sizeof(double) * e->S, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	std::memcpy(out, e->h_result, sizeof(double) * e->S);
 	return PHYAMD_OK;
 }
 

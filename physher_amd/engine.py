@@ -133,6 +133,30 @@ class Engine:
         self._check(self._lib.phyamd_root_invariant_term(self._h, C.byref(v)))
         return v.value
 
+    # --- substitution-model gradient (calculate_dlnl_dQ, treelikelihood.c:2337-2583)
+    def set_rate_matrix_derivatives(self, dQ):
+        """dQ [count][S][S]: d(normalised Q)/d(parameter); an empty array clears."""
+        dQ = np.ascontiguousarray(dQ, dtype=np.float64).reshape(-1, self.S, self.S)
+        self._np = dQ.shape[0]
+        self._check(self._lib.phyamd_set_rate_matrix_derivatives(self._h, self._np, _ptr(dQ)))
+
+    def parameter_gradient(self, flags=0):
+        """(lnL, cat_gradient [N][C], parameter_gradient [count]) from one post-order + one pre-order pass."""
+        lnl = C.c_double()
+        g = np.empty((self.N, self.C))
+        pg = np.empty(getattr(self, "_np", 0))
+        self._check(self._lib.phyamd_parameter_gradient(self._h, flags, C.byref(lnl), _ptr(g), _ptr(pg)))
+        return lnl.value, g, pg
+
+    def parameter_gradient_device(self, device_ptr, flags=0):
+        """[lnL | cat gradient | parameter gradient | root frequency term] -> device buffer (1 + N*C + count + S doubles)."""
+        self._check(self._lib.phyamd_parameter_gradient_device(self._h, flags, C.c_void_p(device_ptr)))
+
+    def root_frequency_term(self):
+        a = np.empty(self.S)
+        self._check(self._lib.phyamd_root_frequency_term(self._h, _ptr(a)))
+        return a
+
     def synchronize(self):
         self._check(self._lib.phyamd_synchronize(self._h))
 

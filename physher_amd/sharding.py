@@ -37,7 +37,7 @@ def all_reduce_result(result, world: int, via_host: bool = False):
 def epilogue(result: np.ndarray, node_count: int, cat_rates, cat_props):
     """[lnL, g[node][cat]] -> (lnL, branch gradient [node]): gradient_branch_length_from_cat_inplace."""
     C = len(cat_rates)
-    cg = np.asarray(result[1:]).reshape(node_count, C)
+    cg = np.asarray(result[1:1 + node_count * C]).reshape(node_count, C)
     if C == 1:
         return float(result[0]), cg[:, 0].copy()
     return float(result[0]), (cg * (np.asarray(cat_props) * np.asarray(cat_rates))[None, :]).sum(axis=1)
@@ -50,7 +50,10 @@ class ShardedLikelihood:
     Engine.gradient_device(out.data_ptr()) -- the HIP kernels -- and in the CPU tests a stand-in.
     """
 
-    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False):
+    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False, tail=0):
+        """tail > 0: the vector carries `tail` more per-shard sums after the cat-gradient (Engine.parameter_gradient_device:
+        substitution-parameter sums, then the root frequency term); they ride in the same all-reduce and are returned third."""
+        self.tail = tail
         self.via_host = via_host
         self.evaluate_shard = evaluate_shard
         self.N = node_count
@@ -63,4 +66,7 @@ class ShardedLikelihood:
         self.evaluate_shard(self.result)
         all_reduce_result(self.result, self.world, self.via_host)
         host = self.result.detach().cpu().numpy()
-        return epilogue(host, self.N, self.cat_rates, self.cat_props)
+        lnl, grad = epilogue(host, self.N, self.cat_rates, self.cat_props)
+        if self.tail:
+            return lnl, grad, host[1 + self.N * len(self.cat_rates):][:self.tail].copy()
+        return lnl, grad

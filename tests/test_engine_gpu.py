@@ -387,3 +387,93 @@ def test_generic_full_size_properties(S, T, P, C):
             bl[n] -= 2 * h
             e.set_branch_lengths(bl); dn = e.log_likelihood()
             assert abs((up - dn) / (2 * h) - bg[n]) <= 1e-4 * max(1.0, abs(bg[n]))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# substitution-model gradient: phyamd_parameter_gradient + phyamd_root_frequency_term
+# ---------------------------------------------------------------------------------------------------------
+SUBST_CASES = [c for c in CASES4 if read_spec(c)["model"] in ("gtr", "hky")]
+
+
+def _host_dq(case, gold):
+    from physher_amd import _phycpp_amd as pc
+    spec = read_spec(case)
+    f = list(gold["frequencies"])
+    m = pc.HKYInterface(float(spec["rates"]), f) if spec["model"] == "hky" else pc.GTRInterface([float(x) for x in spec["rates"].split(",")], f)
+    return m.rate_matrix_derivatives()
+
+
+@pytest.mark.parametrize("case", SUBST_CASES)
+def test_golden_parameter_gradient(case):
+    """Engine-level: all parameters in one pre-order pass, fused and unfused schedules, rescaled cases included,
+    against the reference's gradient_all tail and the oracle restatement."""
+    gold = load(case)
+    dQ = _host_dq(case, gold)
+    n_rates = len(dQ) - 4
+    ref = gold["gradient_all"][-len(dQ):]
+    pb = oracle_problem(case, gold)
+    _, og = po.parameter_gradient(pb, dQ)
+    orf = po.root_frequency_term(pb)
+    with engine_from_problem(pb, rescale=_rescale(case), tip_mode=_tip_mode(case)) as e:
+        e.set_rate_matrix_derivatives(dQ)
+        lnl, cg, pg = e.parameter_gradient()
+        rf = e.root_frequency_term()
+        assert e.rescaling == gold["rescaled"]
+        assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+        np.testing.assert_allclose(rf, orf, rtol=1e-11)
+        np.testing.assert_allclose(pg, og, rtol=1e-9, atol=1e-9)
+        full = pg.copy()
+        full[n_rates:] += rf
+        np.testing.assert_allclose(full, ref, rtol=2e-8, atol=1e-7)
+        # the branch gradient that comes with it is the one phyamd_gradient gives
+        lnl2, cg2 = e.gradient()
+        assert lnl2 == lnl and np.array_equal(cg, cg2)
+        # unfused schedule (every node stored) gives the same sums up to rounding
+        e.set_keep_partials(True)
+        _, _, pg_u = e.parameter_gradient()
+        np.testing.assert_allclose(pg_u, pg, rtol=1e-11, atol=1e-10)
+        # a subset of the parameters, and bitwise reproducibility
+        e.set_rate_matrix_derivatives(dQ[:1])
+        _, _, p1 = e.parameter_gradient()
+        _, _, p1b = e.parameter_gradient()
+        assert p1.shape == (1,) and p1[0] == p1b[0] and abs(p1[0] - pg_u[0]) <= 1e-11 * max(1.0, abs(pg_u[0]))
+
+
+@pytest.mark.parametrize("T,P,C,shape,rescale", [(33, 1500, 4, "random", 0), (64, 700, 1, "caterpillar", 0), (40, 333, 8, "balanced", 0),
+                                                 (150, 400, 4, "random", 1), (21, 200, 16, "random", 0), (12, 90, 2, "random", 1)])
+def test_parameter_gradient_random_problems(T, P, C, shape, rescale):
+    """Seeded synthetic problems (ragged pattern counts, 1..16 categories, gaps) against the oracle; 9 parameters with 16
+    categories need more LDS accumulators than one workgroup holds, which exercises the chunked passes."""
+    pb = random_problem(T, P, C, seed=T * 1000 + P, shape=shape, gaps=0.05, rescale=rescale)
+    rng = np.random.default_rng(7)
+    dQ = rng.normal(size=(9, 4, 4))
+    dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(4)[None]  # rows sum to zero like any dQ/dtheta
+    _, og = po.parameter_gradient(pb, dQ)
+    orf = po.root_frequency_term(pb)
+    with engine_from_problem(pb, rescale=rescale) as e:
+        e.set_rate_matrix_derivatives(dQ)
+        lnl, cg, pg = e.parameter_gradient()
+        assert e.rescaling == bool(rescale)
+        scale = max(1.0, np.abs(og).max())
+        assert np.abs(pg - og).max() <= 1e-9 * scale
+        np.testing.assert_allclose(e.root_frequency_term(), orf, rtol=1e-10)
+        ref = pb.gradient()
+        assert np.abs(cg - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+
+
+def test_parameter_gradient_argument_checks():
+    pb = random_problem(8, 100, 2, seed=3)
+    with engine_from_problem(pb) as e:
+        with pytest.raises(EngineError):
+            e.parameter_gradient()  # no dQ set
+        e.set_rate_matrix_derivatives(np.zeros((2, 4, 4)))
+        with pytest.raises(EngineError):
+            e.parameter_gradient(GRAD_FOLD_ROOT_FREQS)
+        lnl, cg, pg = e.parameter_gradient()
+        assert np.all(pg == 0.0)
+        with pytest.raises(EngineError):
+            e.set_rate_matrix_derivatives(np.zeros((65, 4, 4)))
+    pb20 = random_problem(6, 50, 1, seed=4, S=20)
+    with engine_from_problem(pb20) as e:
+        with pytest.raises(EngineError):
+            e.set_rate_matrix_derivatives(np.zeros((1, 20, 20)))

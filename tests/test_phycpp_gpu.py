@@ -106,8 +106,85 @@ def test_parameter_updates_propagate():
     subst.set_rates(np.array([1.2, 3.1, 0.7, 0.9, 2.8]))
     subst.set_frequencies(np.array(gold["frequencies"]))
     assert abs(tlk.log_likelihood() - l0) <= 1e-11 * abs(l0)
-    with pytest.raises(pc.PhyamdError):
-        tlk.request_gradient([pc.TreeLikelihoodGradientFlags.SUBSTITUTION_MODEL])  # loud: not built yet
+
+
+def test_substitution_gradient_refused_without_parameters():
+    from physher_amd import _phycpp_amd as pc
+    gold, tree, subst, site, tlk = _build("jc69_t12", pc)
+    with pytest.raises(pc.PhyamdError):  # JC69 has no dPdp in the reference either
+        tlk.request_gradient([pc.TreeLikelihoodGradientFlags.SUBSTITUTION_MODEL])
+
+
+SUBST_CASES = [c for c in CASES4 if read_spec(c)["model"] in ("gtr", "hky")]
+
+
+@pytest.mark.parametrize("case", SUBST_CASES)
+def test_substitution_model_gradient(case):
+    """SUBSTITUTION_MODEL / _RATES / _FREQUENCIES blocks of the reference's gradient (gradient_PMatrix,
+    treelikelihood.c:3077-3110; calculate_dlnl_dQ :2337-2583), computed here in the same two passes as the branch gradient."""
+    from physher_amd import _phycpp_amd as pc
+    F = pc.TreeLikelihoodGradientFlags
+    gold, tree, subst, site, tlk = _build(case, pc)
+    N = gold["node_count"]
+    n_rates = {"gtr": 5, "hky": 1}[read_spec(case)["model"]]
+    n_site = gold["site_rate_parameters"] + int(gold["site_has_pinv"]) + int(gold["site_has_mu"])
+    ref = gold["gradient_all"]
+    assert gold["gradient_all_flags"] & 4 and len(ref) == N + n_site + n_rates + 4
+    tol = dict(rtol=2e-8, atol=1e-7)
+    tlk.request_gradient([F.TREE_HEIGHT, F.SITE_MODEL, F.SUBSTITUTION_MODEL])
+    assert tlk.gradient_length == N - 2 + n_site + n_rates + 4
+    g = tlk.gradient()
+    np.testing.assert_allclose(g[N - 2 + n_site:], ref[N + n_site:], **tol)
+    np.testing.assert_allclose(g[N - 2: N - 2 + n_site], ref[N: N + n_site], rtol=2e-7, atol=1e-7)
+    tlk.request_gradient([F.SUBSTITUTION_MODEL_RATES])
+    assert tlk.gradient_length == n_rates
+    np.testing.assert_allclose(tlk.gradient(), ref[N + n_site: N + n_site + n_rates], **tol)
+    tlk.request_gradient([F.SUBSTITUTION_MODEL_FREQUENCIES])
+    assert tlk.gradient_length == 4
+    np.testing.assert_allclose(tlk.gradient(), ref[N + n_site + n_rates:], **tol)
+    # default request = everything differentiable (TreeLikelihood_initialize_gradient(flags = 0), treelikelihood.c:255-270)
+    tlk.request_gradient()
+    assert tlk.gradient_length == N - 2 + n_site + n_rates + 4
+    # reference-compatibility mode keeps the substitution block (the reference clears include_root_freqs itself)
+    tlk.request_gradient([F.TREE_HEIGHT, F.SUBSTITUTION_MODEL])
+    tlk.set_reference_compatibility(True)
+    gc = tlk.gradient()
+    np.testing.assert_allclose(gc[N - 2:], ref[N + n_site:], **tol)
+
+
+def test_substitution_gradient_is_a_derivative():
+    """Central differences of the GPU lnL through the wrapper's setters (rates, kappa; frequencies as free coordinates)."""
+    from physher_amd import _phycpp_amd as pc
+    F = pc.TreeLikelihoodGradientFlags
+    for case, n_rates in (("gtr_g4_t16", 5), ("hky_g3_t10", 1)):
+        gold, tree, subst, site, tlk = _build(case, pc)
+        tlk.request_gradient([F.SUBSTITUTION_MODEL])
+        g = tlk.gradient()
+        spec = read_spec(case)
+        r0 = np.array([float(x) for x in spec["rates"].split(",")])
+        set_rates = (lambda r: subst.set_kappa(float(r[0]))) if n_rates == 1 else subst.set_rates
+        h = 1e-5
+        for i in range(n_rates):
+            e = np.zeros(n_rates)
+            e[i] = h
+            set_rates(r0 + e)
+            up = tlk.log_likelihood()
+            set_rates(r0 - e)
+            dn = tlk.log_likelihood()
+            fd = (up - dn) / (2 * h)
+            assert abs(fd - g[i]) <= 2e-5 * max(1.0, abs(fd)), (case, i, fd, g[i])
+        set_rates(r0)
+        # the frequency entries are partial derivatives with the four values free; along a direction that keeps the sum
+        # at 1 they combine into the derivative the simplex setter can realise
+        f0 = np.array(gold["frequencies"])
+        d = np.array([1.0, -1.0, 0.5, -0.5])
+        subst.set_frequencies(f0 + h * d)
+        up = tlk.log_likelihood()
+        subst.set_frequencies(f0 - h * d)
+        dn = tlk.log_likelihood()
+        subst.set_frequencies(f0)
+        fd = (up - dn) / (2 * h)
+        assert abs(fd - g[n_rates:] @ d) <= 2e-5 * max(1.0, abs(fd)), (case, fd, g[n_rates:] @ d)
 
 
 def _fluA(pc, include_jacobian):

@@ -47,6 +47,20 @@ def _worker(rank, world, port, out_dir):
     full = pb.gradient()
     ref_bg = po.branch_gradient_from_cat(full["cat_grad"], pb.cat_rates, pb.cat_props)
     ok = abs(lnl - full["lnl"]) <= 1e-11 * abs(full["lnl"]) and np.abs(bg - ref_bg).max() <= 1e-10 * max(1.0, np.abs(ref_bg).max())
+    # the substitution-parameter sums and the root frequency term are per-pattern sums too: they ride in the same all-reduce
+    rng = np.random.default_rng(5)
+    dQ = rng.normal(size=(3, 4, 4))
+    dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(4)[None]
+
+    def evaluate_shard_params(out):
+        evaluate_shard(out[: 1 + pb.N * pb.C])
+        out[1 + pb.N * pb.C: 1 + pb.N * pb.C + 3] = torch.from_numpy(po.parameter_gradient(sub, dQ)[1])
+        out[1 + pb.N * pb.C + 3:] = torch.from_numpy(po.root_frequency_term(sub))
+
+    buf2 = torch.zeros(1 + pb.N * pb.C + 3 + 4, dtype=torch.float64)
+    lnl2, bg2, tail = ShardedLikelihood(evaluate_shard_params, pb.N, pb.cat_rates, pb.cat_props, world, buf2, tail=7)()
+    ref_tail = np.concatenate([po.parameter_gradient(pb, dQ)[1], po.root_frequency_term(pb)])
+    ok = ok and lnl2 == lnl and np.array_equal(bg2, bg) and np.abs(tail - ref_tail).max() <= 1e-10 * max(1.0, np.abs(ref_tail).max())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate([[float(ok), lnl, hi - lo], bg]))
     dist.barrier()
     dist.destroy_process_group()
