@@ -336,6 +336,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
+                         # real HBM rate of the same launches: PMC bytes (profiles/traffic_latest.json) / HIP-event time.  `achieved`
+                         # counts the reference's three-pass bytes, most of which this design never moves, hence frac > 1
+                         "hbm_measured": None if traffic is None or prof["upper_ms"] <= 0 else
+                                         {"GB/s": traffic * launches / (prof["upper_ms"] * 1e-3) / 1e9,
+                                          "frac_of_peak": traffic * launches / (prof["upper_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "algorithmic_bytes_per_launch": upper_b / launches, "launches_per_eval": launches,
                          "avg_launch_ms": prof["upper_ms"] / launches,
                          "lower_kernel": {"kernel": f"k_lower{kern}", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
