@@ -62,7 +62,7 @@ typedef struct {
 	int32_t state_count;    /* S: 4 (nucleotides), 20 (amino acids), 60 / 61 (codons); others -> PHYAMD_EUNSUPPORTED */
 	int32_t category_count; /* C */
 	int32_t device;         /* HIP device ordinal; -1 = current device */
-	int32_t rescale;        /* PHYAMD_RESCALE_* (rescaling kernels exist for S == 4; other S: NEVER or AUTO, which then never switches) */
+	int32_t rescale;        /* PHYAMD_RESCALE_* (all state counts) */
 	int64_t max_device_bytes; /* 0 = no cap.  A cap below the engine's need makes phyamd_create fail with PHYAMD_ENOMEM
 	                             (processing the patterns in tiles that fit is not built yet: shard across engines instead) */
 	void *stream;           /* hipStream_t to run on, NULL = engine-owned stream */

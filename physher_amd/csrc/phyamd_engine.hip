@@ -701,6 +701,8 @@ struct phyamd_engine {
 	double *d_dptab = nullptr;       // [np][T][C][16][4]
 	double *d_ppart = nullptr;       // [np][upper ops][nblk] per-workgroup parameter sums, then [np][upper ops]
 	double *d_rf_part = nullptr;     // [S][blocks] partial sums of k_root_frequency_term, then [S]
+	double *d_gen_scratch = nullptr; // rescaled S != 4 path: per-level maxima / numerators / denominators
+	size_t gen_scratch_alloc = 0;
 	size_t np_alloc = 0, ppart_alloc = 0;
 	bool params_dirty = true;
 	double *d_model = nullptr, *d_freqs = nullptr, *d_rates = nullptr, *d_props = nullptr, *d_lengths = nullptr, *d_weights = nullptr;
@@ -1055,55 +1057,99 @@ int launch_upper_params_w(phyamd_engine *e, int flags) {
 }
 
 // ---- S != 4: MFMA kernels -----------------------------------------------------------------------------------
-template <int RT, int KT>
+// scratch of the rescaled S != 4 path: per op of a level, 5 rows [C][P] (lower: 1 row of maxima; upper: 3 rows num_l,
+// num_r, den + 2 rows of maxima)
+int ensure_gen_scale_storage(phyamd_engine *e) {
+	int widest = 1;
+	for (size_t i = 0; i + 1 < e->lower_level_off.size(); i++) widest = std::max(widest, e->lower_level_off[i + 1] - e->lower_level_off[i]);
+	for (size_t i = 0; i + 1 < e->upper_level_off.size(); i++) widest = std::max(widest, e->upper_level_off[i + 1] - e->upper_level_off[i]);
+	const size_t need = (size_t)widest * 5 * e->C * e->P;
+	if (e->d_gen_scratch && e->gen_scratch_alloc >= need) return PHYAMD_OK;
+	dev_free(e, &e->d_gen_scratch, e->gen_scratch_alloc);
+	e->gen_scratch_alloc = 0;
+	int rc = dev_alloc(e, &e->d_gen_scratch, need);
+	if (rc) return rc;
+	e->gen_scratch_alloc = need;
+	return PHYAMD_OK;
+}
+
+template <int RT, int KT, bool SCALE>
 int launch_lower_gen(phyamd_engine *e) {
 	const int levels = (int)e->lower_level_off.size() - 1;
 	const size_t lds = sizeof(double) * 2 * MatImage<RT, KT>::SIZE;
 	int rc;
-	if ((rc = allow_big_lds(k_lower_gen<RT, KT, true>, lds)) || (rc = allow_big_lds(k_lower_gen<RT, KT, false>, lds))) return rc;
+	if ((rc = allow_big_lds(k_lower_gen<RT, KT, true, SCALE>, lds)) || (rc = allow_big_lds(k_lower_gen<RT, KT, false, SCALE>, lds))) return rc;
+	if (SCALE && (rc = ensure_gen_scale_storage(e))) return rc;
+	const int pblocks = (e->P + 255) / 256;
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->lower_level_off[lv], cnt = e->lower_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		dim3 grid(e->nblk, cnt, e->C);
-		if (lv == levels - 1)
-			hipLaunchKernelGGL((k_lower_gen<RT, KT, true>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc);
+		const bool is_root = lv == levels - 1;
+		if (is_root)
+			hipLaunchKernelGGL((k_lower_gen<RT, KT, true, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
 		else
-			hipLaunchKernelGGL((k_lower_gen<RT, KT, false>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc);
+			hipLaunchKernelGGL((k_lower_gen<RT, KT, false, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
+		if (SCALE)
+			hipLaunchKernelGGL(k_scale_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->d_lower_ops + off, e->P, e->Pp, e->S, e->C, e->d_lower, e->d_gen_scratch,
+			                   e->d_lscale, is_root ? e->d_Lc : (double *)nullptr);
 	}
-	hipLaunchKernelGGL(k_root_finish, dim3(e->nblk_root), dim3(256), 0, e->stream, e->P, e->C, e->d_Lc, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
+	const double *lscale_root = SCALE ? e->d_lscale + (size_t)e->core_index[e->root] * e->P : nullptr;
+	hipLaunchKernelGGL(k_root_finish, dim3(e->nblk_root), dim3(256), 0, e->stream, e->P, e->C, e->d_Lc, e->d_weights, lscale_root, e->d_plk, e->d_wl, e->d_lnl_part);
 	HIP_TRY(hipGetLastError());
 	e->prof.lower_launches = levels;
 	return PHYAMD_OK;
 }
 
-template <int RT, int KT>
-int launch_upper_gen(phyamd_engine *e, int flags) {
+template <int RT, int KT, bool FOLD, bool SCALE>
+int launch_upper_gen_v(phyamd_engine *e, bool compat) {
 	const int levels = (int)e->upper_level_off.size() - 1;
 	const size_t lds = sizeof(double) * (4 * MatImage<RT, KT>::SIZE + 2 * GenGeo<RT>::WAVES);
-	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS;
 	int rc;
-	if ((rc = allow_big_lds(k_upper_gen<RT, KT, true>, lds)) || (rc = allow_big_lds(k_upper_gen<RT, KT, false>, lds))) return rc;
+	if ((rc = allow_big_lds(k_upper_gen<RT, KT, FOLD, SCALE>, lds))) return rc;
+	if (SCALE && (rc = ensure_gen_scale_storage(e))) return rc;
+	const int pblocks = (e->P + 255) / 256;
+	double *nd = e->d_gen_scratch, *mxu = SCALE ? e->d_gen_scratch : nullptr;
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = e->upper_level_off[lv], cnt = e->upper_level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		dim3 grid(e->nblk, cnt, e->C);
-		if (fold)
-			hipLaunchKernelGGL((k_upper_gen<RT, KT, true>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk);
-		else
-			hipLaunchKernelGGL((k_upper_gen<RT, KT, false>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk);
+		if (SCALE) mxu = e->d_gen_scratch + (size_t)cnt * 3 * e->C * e->P;
+		hipLaunchKernelGGL((k_upper_gen<RT, KT, FOLD, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk, nd, mxu);
+		if (SCALE) {
+			hipLaunchKernelGGL(k_scale_upper_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->d_upper_ops + off, e->P, e->Pp, e->S, e->C, e->d_upper, mxu);
+			const int ppb = GenGeo<RT>::PATTERNS_PER_BLOCK;
+			if (compat)
+				hipLaunchKernelGGL(k_scaled_gradient_gen<true>, dim3(e->nblk, cnt), dim3(256), 0, e->stream, e->d_upper_ops + off, e->P, e->C, ppb, nd, e->d_weights,
+				                   e->d_props, e->d_gpart, e->nblk);
+			else
+				hipLaunchKernelGGL(k_scaled_gradient_gen<false>, dim3(e->nblk, cnt), dim3(256), 0, e->stream, e->d_upper_ops + off, e->P, e->C, ppb, nd, e->d_weights,
+				                   e->d_props, e->d_gpart, e->nblk);
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = levels;
 	return PHYAMD_OK;
 }
 
+template <int RT, int KT>
+int launch_upper_gen(phyamd_engine *e, int flags) {
+	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS, compat = flags & PHYAMD_GRAD_COMPAT_SCALED;
+	if (e->scaling_on) return fold ? launch_upper_gen_v<RT, KT, true, true>(e, compat) : launch_upper_gen_v<RT, KT, false, true>(e, compat);
+	return fold ? launch_upper_gen_v<RT, KT, true, false>(e, false) : launch_upper_gen_v<RT, KT, false, false>(e, false);
+}
+
+template <int RT, int KT>
+int launch_lower_gen_s(phyamd_engine *e) {
+	return e->scaling_on ? launch_lower_gen<RT, KT, true>(e) : launch_lower_gen<RT, KT, false>(e);
+}
+
 // workgroups hold C*G waves; the bound is a template parameter so small groups are not register-capped for 1024 threads
 int launch_lower(phyamd_engine *e) {
-	if (e->generic) return e->S == 20 ? launch_lower_gen<2, 5>(e) : e->S == 60 ? launch_lower_gen<4, 15>(e) : launch_lower_gen<4, 16>(e);
+	if (e->generic) return e->S == 20 ? launch_lower_gen_s<2, 5>(e) : e->S == 60 ? launch_lower_gen_s<4, 15>(e) : launch_lower_gen_s<4, 16>(e);
 	const int waves = e->C * e->G;
 	return waves <= 4 ? launch_lower_w<4>(e) : waves <= 8 ? launch_lower_w<8>(e) : launch_lower_w<16>(e);
 }
@@ -1145,7 +1191,7 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->generic ? e->nblk_root : e->nblk_lower, (const uint8_t *)nullptr,
 		                   e->d_result);
 		HIP_TRY(hipGetLastError());
-		if (e->cfg.rescale != PHYAMD_RESCALE_AUTO || e->scaling_on || !need_host_check || e->generic) break;
+		if (e->cfg.rescale != PHYAMD_RESCALE_AUTO || e->scaling_on || !need_host_check) break;
 		// lazy switch (treelikelihood.c:1496-1519): +-inf lnL turns rescaling on for good and recomputes
 		HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double), hipMemcpyDeviceToHost, e->stream));
 		HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1298,8 +1344,6 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if (cfg->category_count < 1) return fail(PHYAMD_EINVAL, "category_count must be >= 1 (got %d)", cfg->category_count);
 	if (cfg->state_count != 4 && cfg->state_count != 20 && cfg->state_count != 60 && cfg->state_count != 61)
 		return fail(PHYAMD_EUNSUPPORTED, "state_count %d: kernels are built for 4, 20, 60 and 61 states", cfg->state_count);
-	if (cfg->state_count != 4 && cfg->rescale == PHYAMD_RESCALE_ALWAYS)
-		return fail(PHYAMD_EUNSUPPORTED, "rescaling is only built for the 4-state kernels in this revision");
 	if (cfg->rescale < 0 || cfg->rescale > 2) return fail(PHYAMD_EINVAL, "rescale must be PHYAMD_RESCALE_*");
 	int ndev = 0;
 	HIP_TRY(hipGetDeviceCount(&ndev));
@@ -1399,7 +1443,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})

@@ -58,6 +58,9 @@ CASES = [
     ("jc69_inv_t10", dict(T=10, sites=300, seed=15, datatype="nucleotide", model="jc69", freqs="0.25,0.25,0.25,0.25", categories=1,
                           sitedist="discrete", pinv=0.2)),
     ("mg94_t8", dict(T=8, sites=40, seed=10, datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=1)),
+    ("wag_g4_t60_rescale", dict(T=60, sites=40, seed=16, bl=(0.3, 0.9), datatype="aa", model="wag", categories=4, alpha=0.5, rescale=1, slim=1)),
+    ("wag_g2_t500_autorescale", dict(T=500, sites=10, seed=17, bl=(0.5, 1.5), datatype="aa", model="wag", categories=2, alpha=0.5, slim=1)),
+    ("mg94_t40_rescale", dict(T=40, sites=12, seed=18, bl=(0.3, 0.9), datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=1, rescale=1, slim=1)),
     ("mg94_g2_t6_tipstates", dict(T=6, sites=30, seed=11, datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=2, alpha=0.8, tipstates=1)),
 ]
 
