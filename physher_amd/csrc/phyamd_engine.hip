@@ -65,7 +65,13 @@ constexpr int WAVE = 64;             // lanes per wavefront (gfx950)
 #ifndef PHYAMD_UPPER_MIN_WAVES
 #define PHYAMD_UPPER_MIN_WAVES 6
 #endif
-constexpr int PPT_LOWER = PHYAMD_PPT_LOWER, PPT_UPPER = PHYAMD_PPT_UPPER;
+#ifndef PHYAMD_PPT_WALK
+#define PHYAMD_PPT_WALK 2
+#endif
+#ifndef PHYAMD_PPT_WALK_UPPER
+#define PHYAMD_PPT_WALK_UPPER 4
+#endif
+constexpr int PPT_LOWER = PHYAMD_PPT_LOWER, PPT_UPPER = PHYAMD_PPT_UPPER, PPT_WALK = PHYAMD_PPT_WALK, PPT_WALK_UPPER = PHYAMD_PPT_WALK_UPPER;
 constexpr int MAX_WAVES = 16;        // 1024 threads
 constexpr double SCALING_THRESHOLD = 1.0e-40;  // treelikelihood.c:1121
 
@@ -80,6 +86,10 @@ struct NodeOp {
 	int32_t kind_left, kind_right;               // CH_*
 	int32_t lt0, lt1, lt2, linner;               // left fringe: cherry tips, outer tip, inner cherry node
 	int32_t rt0, rt1, rt2, rinner;               // right fringe
+	// tree-walk kernels only (ops in depth-first order, values handed from one op to the next in registers):
+	int32_t carry_in;   // lower walk: 1 / 2 = the left / right child's partial is the previous op's result;
+	                    // upper walk: 1 = the parent's upper is the previous op's carried child upper
+	int32_t carry_out;  // upper walk: 1 / 2 = the left / right child's upper goes to the next op in registers (not stored)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -358,6 +368,86 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Tree-walk form of the post-order pass (unscaled evaluations).  Patterns are independent, so instead of one launch
+// per tree level a workgroup keeps its 64*G*PPT_WALK patterns and walks ALL core nodes itself, in depth-first
+// post-order (larger subtree first).  The op before a node is then always one of its children: that child's partial
+// is taken from registers instead of being read back (it is still stored once for the pre-order pass), and the other
+// child was written by this very thread a short subtree ago, often still in L2 / Infinity Cache.  One launch, no
+// level barriers; the root's integration happens after the loop on the carried root partial.
+// dynamic LDS: G*C*64 doubles (root exchange) + G doubles
+// ------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *WAVE) void k_lower4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
+                                                             const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
+                                                             const double *__restrict__ mats, const double *__restrict__ tiptab,
+                                                             const double *__restrict__ freqs, const double *__restrict__ props,
+                                                             const double *__restrict__ weights, double *__restrict__ pattern_lk,
+                                                             double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
+	extern __shared__ double sh[];
+	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
+	const size_t plane = (size_t)P * 4;
+	int kq[PPT_WALK];
+	bool vq[PPT_WALK];
+#pragma unroll
+	for (int q = 0; q < PPT_WALK; q++) {
+		const int k0 = ((blockIdx.x * PPT_WALK + q) * G + g) * WAVE + lane;
+		vq[q] = k0 < P;
+		kq[q] = vq[q] ? k0 : P - 1;
+	}
+	d4 carry[PPT_WALK];
+#pragma unroll
+	for (int q = 0; q < PPT_WALK; q++) carry[q] = d4{0., 0., 0., 0.};
+#pragma unroll 1
+	for (int i = 0; i < nops; i++) {
+		const NodeOp *op = ops + i;  // wave-uniform: scalar loads
+		const int cin = op->carry_in;
+		double *dst = lower + ((size_t)op->core_parent * C + c) * plane;
+#pragma unroll
+		for (int q = 0; q < PPT_WALK; q++) {
+			const Ctx4 x{tipmask, mats, tiptab, P, C, c, kq[q]};
+			const d4 a = cin == 1 ? matvec4(x.M(op->left), carry[q])
+			                      : child_message(x, op->kind_left, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
+			const d4 b = cin == 2 ? matvec4(x.M(op->right), carry[q])
+			                      : child_message(x, op->kind_right, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
+			const d4 out = mul4(a, b);
+			if (vq[q]) store4(dst + (size_t)kq[q] * 4, out);
+			carry[q] = out;
+		}
+	}
+	// the last op is the root: integrate_partials + node_log_likelihoods + weighted sum (treelikelihood.c:1473-1487)
+	double acc = 0.0;
+	const int xsz = G * C * WAVE;
+#pragma unroll
+	for (int q = 0; q < PPT_WALK; q++) {
+		const d4 out = carry[q];
+		if (q) __syncthreads();
+		sh[(g * C + c) * WAVE + lane] = props[c] * (freqs[0] * out.x + freqs[1] * out.y + freqs[2] * out.z + freqs[3] * out.w);
+		__syncthreads();
+		if (c == 0) {
+			double L = 0.0;
+			for (int cc = 0; cc < C; cc++) L += sh[(g * C + cc) * WAVE + lane];
+			const double lk = log(L);
+			if (vq[q]) {
+				const double w = weights[kq[q]];
+				pattern_lk[kq[q]] = lk;
+				w_over_L[kq[q]] = w / L;
+				acc += lk * w;
+			}
+		}
+	}
+	double *red = sh + xsz;
+	const double s = wave_sum(acc);
+	if (lane == 0 && c == 0) red[g] = s;
+	__syncthreads();
+	if (lane == 0 && c == 0 && g == 0) {
+		double t = red[0];
+		for (int gg = 1; gg < G; gg++) t += red[gg];
+		lnl_part[blockIdx.x] = t;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // K7 + K8 fused, 4 states: one level of the pre-order pass
 // ------------------------------------------------------------------------------------------------
@@ -410,8 +500,19 @@ struct Grad4 {
 //   CH_CHERRY     : +0 -> t0, +1 -> t1
 //   CH_CHERRY_TIP : +0 -> t0, +1 -> t1 (inside the inner cherry), +2 -> inner, +3 -> t2
 // Ordered so that few vectors are live at once (the kernel is register-limited).
-template <bool PARAMS>
-__device__ __forceinline__ void descend_fringe(const Ctx4 &x, const Grad4 &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
+// the same accumulators held in registers (tree-walk kernel: reduced and flushed after every op)
+struct Grad4R {
+	cptr Q;
+	d4 f;
+	double wl;
+	double acc[16];
+	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) { acc[i] += wl * dot4(mul4(f, u), matvec4(opaque(Q), b)); }
+	__device__ __forceinline__ void addp_vec(const Ctx4 &, int, const d4 &, const d4 &) {}
+	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) {}
+};
+
+template <bool PARAMS, typename GradT>
+__device__ __forceinline__ void descend_fringe(const Ctx4 &x, GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
                                                const d4 &u) {
 	const d4 b0 = x.tipmsg(t0), b1 = x.tipmsg(t1);
 	d4 a2 = matvec4(x.M(node), u);
@@ -575,6 +676,110 @@ __global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER
 	}
 }
 
+// sum 16 per-lane values over the 64 lanes of a wave in 17 exchange steps (instead of 16 x 6): after the xor-32 step a
+// lane keeps only half of the values, after xor-16 a quarter, ...  Returns, in every lane, the wave total of value
+// index ((lane >> 2) & 15) with bits taken as (bit5, bit4, bit3, bit2) -> (8, 4, 2, 1).  Fixed order: deterministic.
+__device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
+	double a8[8], a4[4], a2[2];
+	const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+	for (int i = 0; i < 8; i++) a8[i] = (h5 ? v[i + 8] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 8], 32, 64);
+#pragma unroll
+	for (int i = 0; i < 4; i++) a4[i] = (h4 ? a8[i + 4] : a8[i]) + __shfl_xor(h4 ? a8[i] : a8[i + 4], 16, 64);
+#pragma unroll
+	for (int i = 0; i < 2; i++) a2[i] = (h3 ? a4[i + 2] : a4[i]) + __shfl_xor(h3 ? a4[i] : a4[i + 2], 8, 64);
+	double a1 = (h2 ? a2[1] : a2[0]) + __shfl_xor(h2 ? a2[0] : a2[1], 4, 64);
+	a1 += __shfl_xor(a1, 2, 64);
+	a1 += __shfl_xor(a1, 1, 64);
+	return a1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tree-walk form of the pre-order pass + branch gradient (unscaled evaluations), the counterpart of k_lower4_walk: a
+// workgroup keeps its patterns and visits every core node in depth-first pre-order, smaller core subtree first.  The
+// upper partial of the child visited next never leaves registers (no store, no load); the other core child's upper is
+// parked in one of ~log2(core nodes) recycled slots and read back by the same thread after the small subtree.
+// Per op the NACC branch accumulators are reduced over the wave (wave_sum16) and written to the gradient slab:
+// gpart[(node * C + c) * nblk + blockIdx.x * G + g], nblk = gridDim.x * G.
+// ------------------------------------------------------------------------------------------------
+#ifndef PHYAMD_WALK_UPPER_MIN_WAVES
+#define PHYAMD_WALK_UPPER_MIN_WAVES 4
+#endif
+template <int WAVES, bool FOLD>
+__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAVES : 1) void k_upper4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
+                                                             const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
+                                                             double *__restrict__ upper, const double *__restrict__ mats,
+                                                             const double *__restrict__ tiptab, const double *__restrict__ Q,
+                                                             const double *__restrict__ freqs, const double *__restrict__ w_over_L,
+                                                             double *__restrict__ gpart, int nblk) {
+	extern __shared__ double sh[];  // carried uppers: [PPT_WALK_UPPER][waves][4 components][64 lanes], private to each thread
+	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
+	const size_t plane = (size_t)P * 4;
+	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
+	const d4 one = d4{1., 1., 1., 1.};
+	const int nw = G * C, wv = g * C + c;
+	double *my_carry = sh + (size_t)wv * 4 * WAVE + lane;  // + q * nw * 4 * WAVE, component stride WAVE
+	// which accumulator this lane reports after wave_sum16
+	const int my = ((lane & 32) ? 8 : 0) + ((lane & 16) ? 4 : 0) + ((lane & 8) ? 2 : 0) + ((lane & 4) ? 1 : 0);
+	const size_t slab = (size_t)blockIdx.x * G + g;
+#pragma unroll 1
+	for (int i = 0; i < nops; i++) {
+		const NodeOp *op = ops + i;  // wave-uniform: scalar loads
+		const bool proot = i == 0;   // pre-order: the root comes first
+		const int cin = op->carry_in, cout = op->carry_out;
+		const int kl = op->kind_left, kr = op->kind_right;
+		const double *up = (proot || cin) ? nullptr : upper + ((size_t)op->upper_slot_parent * C + c) * plane;
+		double *ul_dst = op->upper_slot_left < 0 ? nullptr : upper + ((size_t)op->upper_slot_left * C + c) * plane;
+		double *ur_dst = op->upper_slot_right < 0 ? nullptr : upper + ((size_t)op->upper_slot_right * C + c) * plane;
+		Grad4R gr{as_const(Q), FOLD ? one : pi, 0.0, {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.}};
+#pragma unroll 1
+		for (int q = 0; q < PPT_WALK_UPPER; q++) {
+			const int k0 = ((blockIdx.x * PPT_WALK_UPPER + q) * G + g) * WAVE + lane;
+			const bool valid = k0 < P;
+			const int k = valid ? k0 : P - 1;
+			const Ctx4 x{tipmask, mats, tiptab, P, C, c, k};
+			double *cq = my_carry + (size_t)q * nw * 4 * WAVE;
+			const d4 bl = child_message(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
+			const d4 br = child_message(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
+			d4 a;
+			if (proot) a = FOLD ? pi : one;
+			else a = matvec4(x.M(op->parent), cin ? d4{cq[0], cq[WAVE], cq[2 * WAVE], cq[3 * WAVE]} : load4(up + (size_t)k * 4));
+			const d4 ul = mul4(a, br), ur = mul4(a, bl);
+			gr.wl = valid ? w_over_L[k] : 0.0;
+			gr.add(0, ul, bl);
+			gr.add(1, ur, br);
+			if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
+			if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
+			if (cout) {  // the next op's parent upper stays on chip
+				const d4 u = cout == 1 ? ul : ur;
+				cq[0] = u.x;
+				cq[WAVE] = u.y;
+				cq[2 * WAVE] = u.z;
+				cq[3 * WAVE] = u.w;
+			}
+			if (kl >= CH_CHERRY) descend_fringe<false>(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul);
+			if (kr >= CH_CHERRY) descend_fringe<false>(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur);
+		}
+		const double tot = wave_sum16(gr.acc, lane);
+		if ((lane & 3) == 0 && my < NACC) {
+			int node = -1;  // accumulator -> gradient row (node id); -1 = unused for this op
+			switch (my) {
+				case 0: node = op->left; break;
+				case 1: node = op->right; break;
+				case 2: node = kl >= CH_CHERRY ? op->lt0 : -1; break;
+				case 3: node = kl >= CH_CHERRY ? op->lt1 : -1; break;
+				case 4: node = kl == CH_CHERRY_TIP ? op->linner : -1; break;
+				case 5: node = kl == CH_CHERRY_TIP ? op->lt2 : -1; break;
+				case 6: node = kr >= CH_CHERRY ? op->rt0 : -1; break;
+				case 7: node = kr >= CH_CHERRY ? op->rt1 : -1; break;
+				case 8: node = kr == CH_CHERRY_TIP ? op->rinner : -1; break;
+				case 9: node = kr == CH_CHERRY_TIP ? op->rt2 : -1; break;
+			}
+			if (node >= 0) gpart[((size_t)node * C + c) * nblk + slab] = tot;
+		}
+	}
+}
+
 // fixed-order reduction of per-block slabs: one wave per row. out[row_offset + row] = sum_b part[row][b]
 __global__ __launch_bounds__(64) void k_reduce_rows(const double *__restrict__ part, int nblk, const uint8_t *__restrict__ row_valid,
                                                    double *__restrict__ out) {
@@ -659,6 +864,16 @@ struct phyamd_engine {
 	int Pp = 0;            // padded plane stride (generic)
 	int nblk_root = 0;     // workgroups of k_root_finish (generic)
 	int nblk_lower = 0;    // pattern blocks of the post-order kernels
+	int nblk_walk = 0, nblk_walk_upper = 0;  // pattern blocks of the tree-walk kernels
+	int lnl_blocks = 0;    // entries of d_lnl_part the last post-order pass wrote
+	int grad_blocks = 0;   // entries per row of d_gpart the last pre-order pass wrote
+	size_t gpart_row = 0;  // allocated entries per row
+	bool level_upper_needed = false;  // a level-schedule pre-order pass (parameter gradients) has been requested
+	bool walk_lower_on = true, walk_upper_on = true;  // A/B switches (PHYAMD_WALK_LOWER / PHYAMD_WALK_UPPER = 0)
+	bool walk_enabled = true, walking = false;  // tree-walk kernels (4 states, unscaled, not keep_partials)
+	std::vector<NodeOp> walk_lower_ops, walk_upper_ops;  // depth-first op orders
+	NodeOp *d_walk_lower_ops = nullptr, *d_walk_upper_ops = nullptr;
+	int walk_upper_slots = 0;
 	double *d_Lc = nullptr;  // [C][P] per-category site likelihoods at the root (generic)
 	double *d_inv_part = nullptr;  // partial sums of k_root_invariant_term
 	int device = 0;
@@ -878,6 +1093,92 @@ int build_schedule(phyamd_engine *e) {
 		e->upper_level_off.push_back((int)e->upper_ops.size());
 	}
 	e->upper_slots = e->keep_partials ? N : next_slot;
+
+	// Depth-first op orders for the tree-walk kernels (see k_lower4_walk).  csize = core ops in the subtree.
+	e->walking = e->walk_enabled && !e->generic && !e->keep_partials && !e->scaling_on;
+	e->walk_lower_ops.clear();
+	e->walk_upper_ops.clear();
+	e->walk_upper_slots = 0;
+	if (e->walking) {
+		std::vector<int> csize(N, 0);
+		for (int i = N - 1; i >= 0; i--) {
+			const int n = order[i];
+			if (kind[n] == CH_CORE) csize[n] = 1 + csize[e->left[n]] + csize[e->right[n]];
+		}
+		// post-order, larger core subtree first: the op before a node is its second (smaller) core child, or its only one
+		struct Frame {
+			int node, stage;
+		};
+		std::vector<Frame> st{{e->root, 0}};
+		while (!st.empty()) {
+			Frame &f = st.back();
+			const int n = f.node, l = e->left[n], r = e->right[n];
+			const int first = csize[l] >= csize[r] ? l : r, second = first == l ? r : l;
+			if (f.stage == 0) {
+				f.stage = 1;
+				if (kind[first] == CH_CORE) st.push_back({first, 0});
+			} else if (f.stage == 1) {
+				f.stage = 2;
+				if (kind[second] == CH_CORE) st.push_back({second, 0});
+			} else {
+				NodeOp op = make_op(n);
+				op.carry_in = 0;
+				if (!e->walk_lower_ops.empty()) {
+					const int prev = e->walk_lower_ops.back().parent;
+					if (prev == l) op.carry_in = 1;
+					else if (prev == r) op.carry_in = 2;
+				}
+				e->walk_lower_ops.push_back(op);
+				st.pop_back();
+			}
+		}
+		// pre-order, SMALLER core subtree first: the first-visited core child takes its upper in registers (never stored);
+		// the other child's upper waits in a slot while the small subtree is walked (nesting depth <= log2 of the core count)
+		std::vector<int> free_w;
+		int next_w = 0;
+		std::vector<int> slot_of(N, -1);
+		std::vector<int> stack2{e->root};
+		int carried_node = -1;  // node whose upper the previous op carried out
+		while (!stack2.empty()) {
+			const int n = stack2.back();
+			stack2.pop_back();
+			NodeOp op = make_op(n);
+			op.carry_in = (n != e->root && carried_node == n) ? 1 : 0;
+			op.upper_slot_parent = -1;
+			if (n != e->root && !op.carry_in) {
+				op.upper_slot_parent = slot_of[n];
+				free_w.push_back(slot_of[n]);  // read by this op; reusable by ops after it
+			}
+			const int l = e->left[n], r = e->right[n];
+			const bool lc = kind[l] == CH_CORE, rc2 = kind[r] == CH_CORE;
+			int first = -1, second = -1;
+			if (lc && rc2) {
+				first = csize[l] <= csize[r] ? l : r;
+				second = first == l ? r : l;
+			} else if (lc || rc2)
+				first = lc ? l : r;
+			op.carry_out = first < 0 ? 0 : (first == l ? 1 : 2);
+			carried_node = first;
+			if (second >= 0) {
+				int sl;
+				// a slot freed by THIS op (its own parent upper) must not be reused for its output: lanes of other waves may
+				// still be reading it -- not an issue within a thread, but keep it simple and safe: take another one
+				if (free_w.size() > 1 || (free_w.size() == 1 && free_w.back() != op.upper_slot_parent)) {
+					size_t pick = free_w.size() - 1;
+					if (free_w[pick] == op.upper_slot_parent) pick--;
+					sl = free_w[pick];
+					free_w.erase(free_w.begin() + pick);
+				} else
+					sl = next_w++;
+				slot_of[second] = sl;
+				(second == l ? op.upper_slot_left : op.upper_slot_right) = sl;
+				stack2.push_back(second);
+			}
+			if (first >= 0) stack2.push_back(first);  // visited next
+			e->walk_upper_ops.push_back(op);
+		}
+		e->walk_upper_slots = next_w;
+	}
 	return PHYAMD_OK;
 }
 
@@ -900,6 +1201,12 @@ int upload_schedule(phyamd_engine *e) {
 	if (!e->d_upper_ops && (rc = dev_alloc(e, &e->d_upper_ops, (size_t)e->N))) return rc;
 	HIP_TRY(hipMemcpyAsync(e->d_lower_ops, e->lower_ops.data(), e->lower_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipMemcpyAsync(e->d_upper_ops, e->upper_ops.data(), e->upper_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
+	if (e->walking) {
+		if (!e->d_walk_lower_ops && (rc = dev_alloc(e, &e->d_walk_lower_ops, (size_t)e->N))) return rc;
+		if (!e->d_walk_upper_ops && (rc = dev_alloc(e, &e->d_walk_upper_ops, (size_t)e->N))) return rc;
+		HIP_TRY(hipMemcpyAsync(e->d_walk_lower_ops, e->walk_lower_ops.data(), e->walk_lower_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipMemcpyAsync(e->d_walk_upper_ops, e->walk_upper_ops.data(), e->walk_upper_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
+	}
 	// rows of the gradient slab that are produced by the upper pass (every non-root node)
 	std::vector<uint8_t> valid((size_t)e->N * e->C, 1);
 	for (int c = 0; c < e->C; c++) valid[(size_t)e->root * e->C + c] = 0;
@@ -909,7 +1216,10 @@ int upload_schedule(phyamd_engine *e) {
 }
 
 int ensure_upper_storage(phyamd_engine *e) {
-	const size_t need = (size_t)std::max(1, e->upper_slots);
+	// the tree-walk schedule parks far fewer uppers than the level schedule keeps; parameter-gradient and inspection
+	// calls still run the level kernels, so the larger of the two is held once either has been needed
+	const bool level_path = !(e->walking && e->walk_upper_on) || e->level_upper_needed;
+	const size_t need = (size_t)std::max(1, level_path ? std::max(e->upper_slots, e->walk_upper_slots) : e->walk_upper_slots);
 	if (e->d_upper && e->upper_alloc_slots >= need) return PHYAMD_OK;
 	dev_free(e, &e->d_upper, e->upper_alloc_slots * node_partial_doubles(e));
 	e->upper_alloc_slots = 0;
@@ -981,11 +1291,24 @@ int launch_lower_levels(phyamd_engine *e) {
 	}
 	HIP_TRY(hipGetLastError());
 	e->prof.lower_launches = launched;
+	e->lnl_blocks = e->nblk_lower;
+	return PHYAMD_OK;
+}
+
+template <int WAVES>
+int launch_lower_walk(phyamd_engine *e) {
+	const size_t lds = sizeof(double) * ((size_t)e->G * e->C * WAVE + e->G);
+	hipLaunchKernelGGL((k_lower4_walk<WAVES>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(), e->T, e->P,
+	                   e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
+	HIP_TRY(hipGetLastError());
+	e->prof.lower_launches = 1;
+	e->lnl_blocks = e->nblk_walk;
 	return PHYAMD_OK;
 }
 
 template <int WAVES>
 int launch_lower_w(phyamd_engine *e) {
+	if (e->walking && !e->scaling_on && e->walk_lower_on) return launch_lower_walk<WAVES>(e);
 	return e->scaling_on ? launch_lower_levels<WAVES, true>(e) : launch_lower_levels<WAVES, false>(e);
 }
 
@@ -1023,8 +1346,26 @@ int launch_upper_levels(phyamd_engine *e, int p0 = 0, int pc = 0) {
 }
 
 template <int WAVES>
+int launch_upper_walk(phyamd_engine *e, bool fold) {
+	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G;
+	const size_t lds = sizeof(double) * PPT_WALK_UPPER * e->G * e->C * 4 * WAVE;
+	if (fold)
+		hipLaunchKernelGGL((k_upper4_walk<WAVES, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C, e->d_tipmask,
+		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
+	else
+		hipLaunchKernelGGL((k_upper4_walk<WAVES, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C, e->d_tipmask,
+		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
+	HIP_TRY(hipGetLastError());
+	e->prof.upper_launches = 1;
+	e->grad_blocks = nb;
+	return PHYAMD_OK;
+}
+
+template <int WAVES>
 int launch_upper_w(phyamd_engine *e, int flags) {
 	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS, compat = (flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on;
+	e->grad_blocks = e->nblk;
+	if (e->walking && !e->scaling_on && e->walk_upper_on) return launch_upper_walk<WAVES>(e, fold);
 	if (e->scaling_on) {
 		if (fold) return compat ? launch_upper_levels<WAVES, true, true, true, false>(e) : launch_upper_levels<WAVES, true, true, false, false>(e);
 		return compat ? launch_upper_levels<WAVES, true, false, true, false>(e) : launch_upper_levels<WAVES, true, false, false, false>(e);
@@ -1188,7 +1529,7 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 	if (e->scaling_on && (rc = ensure_scaling_storage(e))) return rc;
 	for (int attempt = 0; attempt < 2; attempt++) {
 		if ((rc = launch_lower(e))) return rc;
-		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->generic ? e->nblk_root : e->nblk_lower, (const uint8_t *)nullptr,
+		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->generic ? e->nblk_root : e->lnl_blocks, (const uint8_t *)nullptr,
 		                   e->d_result);
 		HIP_TRY(hipGetLastError());
 		if (e->cfg.rescale != PHYAMD_RESCALE_AUTO || e->scaling_on || !need_host_check) break;
@@ -1284,15 +1625,17 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 			return fail(PHYAMD_EINVAL, "PHYAMD_GRAD_FOLD_ROOT_FREQS cannot be combined with parameter gradients (the reference clears include_root_freqs, treelikelihood.c:291-305)");
 	}
 	if ((rc = run_lower(e, true))) return rc;
+	if (with_params) e->level_upper_needed = true;
 	if ((rc = ensure_upper_storage(e))) return rc;
 	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
+	e->grad_blocks = e->nblk;
 	if (with_params) {
 		if ((rc = update_parameter_matrices(e))) return rc;
 		if ((rc = launch_upper_params(e, flags))) return rc;
 	} else if ((rc = launch_upper(e, flags)))
 		return rc;
 	record(e, 3);
-	hipLaunchKernelGGL(k_reduce_rows, dim3(e->N * e->C), dim3(64), 0, e->stream, e->d_gpart, e->nblk, e->d_row_valid, e->d_result + 1);
+	hipLaunchKernelGGL(k_reduce_rows, dim3(e->N * e->C), dim3(64), 0, e->stream, e->d_gpart, e->grad_blocks, e->d_row_valid, e->d_result + 1);
 	if (with_params) {  // [np][ops][nblk] -> [np][ops] -> [np], fixed order
 		const int ops = (int)e->upper_ops.size();
 		double *stage = e->d_ppart + (size_t)e->np * ops * e->nblk;
@@ -1384,6 +1727,11 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	e->G = std::max(1, 4 / e->C);  // at least 4 waves per workgroup
 	e->nblk = (e->P + WAVE * e->G * PPT_UPPER - 1) / (WAVE * e->G * PPT_UPPER);        // pre-order kernel / gradient slabs
 	e->nblk_lower = (e->P + WAVE * e->G * PPT_LOWER - 1) / (WAVE * e->G * PPT_LOWER);  // post-order kernel / lnL slab
+	e->nblk_walk = (e->P + WAVE * e->G * PPT_WALK - 1) / (WAVE * e->G * PPT_WALK);
+	e->nblk_walk_upper = (e->P + WAVE * e->G * PPT_WALK_UPPER - 1) / (WAVE * e->G * PPT_WALK_UPPER);
+	if (const char *env = std::getenv("PHYAMD_WALK")) e->walk_enabled = std::atoi(env) != 0;
+	if (const char *env = std::getenv("PHYAMD_WALK_LOWER")) e->walk_lower_on = std::atoi(env) != 0;
+	if (const char *env = std::getenv("PHYAMD_WALK_UPPER")) e->walk_upper_on = std::atoi(env) != 0;
 	e->generic = e->S != 4;
 	if (e->generic) {
 		e->Pp = (e->P + 15) / 16 * 16;
@@ -1417,9 +1765,10 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if ((rc = dev_alloc(e, &e->d_weights, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_plk, (size_t)e->P))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_wl, (size_t)e->P))) return bail(rc);
-	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)std::max(std::max(e->nblk, e->nblk_lower), e->nblk_root)))) return bail(rc);
+	if ((rc = dev_alloc(e, &e->d_lnl_part, (size_t)std::max(std::max(std::max(e->nblk, e->nblk_lower), e->nblk_walk), e->nblk_root)))) return bail(rc);
 	if (e->generic && (rc = dev_alloc(e, &e->d_Lc, (size_t)e->C * e->P))) return bail(rc);
-	if ((rc = dev_alloc(e, &e->d_gpart, (size_t)e->N * e->C * e->nblk))) return bail(rc);
+	e->gpart_row = (size_t)std::max(e->nblk, e->generic ? 0 : e->nblk_walk_upper * e->G);  // the tree-walk kernels write one entry per wave-group
+	if ((rc = dev_alloc(e, &e->d_gpart, (size_t)e->N * e->C * e->gpart_row))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_result, (size_t)1 + e->N * e->C + 2 * PHYAMD_MAX_PARAMETERS))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_explicit, (size_t)e->N))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_row_valid, (size_t)e->N * e->C))) return bail(rc);
@@ -1427,7 +1776,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 		hipError_t err = hipHostMalloc(reinterpret_cast<void **>(&e->h_result), sizeof(double) * ((size_t)1 + e->N * e->C + 2 * PHYAMD_MAX_PARAMETERS), hipHostMallocDefault);
 		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "hipHostMalloc: %s", hipGetErrorString(err)));
 		err = hipMemsetAsync(e->d_explicit, 0, e->N, e->stream);
-		if (err == hipSuccess) err = hipMemsetAsync(e->d_gpart, 0, sizeof(double) * (size_t)e->N * e->C * e->nblk, e->stream);
+		if (err == hipSuccess) err = hipMemsetAsync(e->d_gpart, 0, sizeof(double) * (size_t)e->N * e->C * e->gpart_row, e->stream);
 		if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
 		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "memset: %s", hipGetErrorString(err)));
 		for (auto &ev : e->ev) {
@@ -1446,7 +1795,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	for (void *p : {(void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
-	                (void *)e->d_lower_ops, (void *)e->d_upper_ops})
+	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops})
 		if (p) (void)hipFree(p);
 	if (e->h_result) (void)hipHostFree(e->h_result);
 	for (auto &ev : e->ev)

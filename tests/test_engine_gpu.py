@@ -461,8 +461,8 @@ def test_golden_parameter_gradient(case):
         full[n_rates:] += rf
         np.testing.assert_allclose(full, ref, rtol=2e-8, atol=1e-7)
         # the branch gradient that comes with it is the one phyamd_gradient gives
-        lnl2, cg2 = e.gradient()
-        assert lnl2 == lnl and np.array_equal(cg, cg2)
+        lnl2, cg2 = e.gradient()  # (the tree-walk kernels: another summation order)
+        assert lnl2 == lnl and np.abs(cg - cg2).max() <= 1e-11 * max(1.0, np.abs(cg).max())
         # unfused schedule (every node stored) gives the same sums up to rounding
         e.set_keep_partials(True)
         _, _, pg_u = e.parameter_gradient()
