@@ -302,15 +302,16 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps / elapsed
         lower_b, upper_b = algorithmic_bytes(T, Pl, C, S)  # this rank's shard
-        kern = "4" if S == 4 else "_gen"
         launches = max(1, p["upper_launches"])
+        # 4 states, unscaled: the tree-walk kernels (ONE launch per pass); otherwise one launch per tree level
+        kern = ("4_walk" if launches == 1 and T > 2 else "4") if S == 4 else "_gen"
         achieved = upper_b / (prof["upper_ms"] * 1e-3) / 1e9 if prof["upper_ms"] > 0 else None
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
                 with open(args.traffic_json) as f:
                     tj = json.load(f)
-                if S == 4 and tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C:
+                if S == 4 and tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C and tj.get("launches_per_eval") == launches:
                     traffic = tj["upper_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -343,7 +344,7 @@ def main():
                                           "frac_of_peak": traffic * launches / (prof["upper_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "algorithmic_bytes_per_launch": upper_b / launches, "launches_per_eval": launches,
                          "avg_launch_ms": prof["upper_ms"] / launches,
-                         "lower_kernel": {"kernel": f"k_lower{kern}", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
+                         "lower_kernel": {"kernel": f"k_lower{kern}" if p["lower_launches"] == 1 or S != 4 else "k_lower4", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
                                           "launches_per_eval": p["lower_launches"], "ms_per_eval": prof["lower_ms"]},
                          "ms_per_eval": {k: prof[k] for k in prof}},
         }

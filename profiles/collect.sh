@@ -29,9 +29,10 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 	rocprofv3 --pmc $ctr --kernel-trace --output-format csv --kernel-include-regex "$KREGEX" -d /tmp/prof_$ctr -o pmc -- $BENCH --steps 1 --warmup 1 > /dev/null 2> "$OUT/pmc_$ctr.err"
 	f=$(find /tmp/prof_$ctr -name 'pmc_counter_collection.csv' | head -1)
 	head -1 "$f" > "$OUT/${TAG}_pmc_$ctr.csv"
-	grep -E "$KREGEX" "$f" | tail -72 >> "$OUT/${TAG}_pmc_$ctr.csv"
+	grep -E "$KREGEX" "$f" | tail -8 >> "$OUT/${TAG}_pmc_$ctr.csv"
 	echo "$ctr done" >&2
 done
 cd "$ROOT"
+unset PHYAMD_BENCH_BLOCK
 python3 bench.py --steps 5 --warmup 2 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 ls -la "$OUT" >&2

@@ -20,7 +20,7 @@ def per_kernel(fn, key, launches):
 
 def main():
     fetch, write, T, P, C, L, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
-    res = {"taxa": T, "patterns": P, "categories": C, "source": [fetch, write],
+    res = {"taxa": T, "patterns": P, "categories": C, "launches_per_eval": L, "source": [fetch, write],
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction)"}
     for name, key in (("upper", "k_upper4"), ("lower", "k_lower4")):
         f, n1 = per_kernel(fetch, key, L)

@@ -255,6 +255,38 @@ def test_fusion_switch_and_memory():
     assert bytes_f < 0.75 * bytes_u
 
 
+@pytest.mark.parametrize("T,P,C,shape", [(300, 2500, 4, "random"), (120, 777, 1, "caterpillar"), (64, 1000, 2, "balanced"), (50, 300, 3, "random"),
+                                         (40, 500, 8, "random"), (33, 129, 16, "random"), (3, 70, 4, "random"), (2, 5, 4, "random")])
+def test_tree_walk_kernels_match_level_kernels(T, P, C, shape):
+    """The depth-first tree-walk kernels (default for unscaled 4-state evaluations: one launch per pass, child/parent
+    partials handed on in registers / LDS) against the level-batched kernels (PHYAMD_WALK=0) and the oracle; fused and
+    unfused fringe; the walk parks far fewer upper partials."""
+    import os
+    pb = random_problem(T, P, C, seed=900 + T + C, shape=shape, gaps=0.03)
+    ref = pb.gradient()
+    res = {}
+    for walk, fuse in ((1, 1), (0, 1), (1, 0)):
+        os.environ["PHYAMD_WALK"], os.environ["PHYAMD_FUSE"] = str(walk), str(fuse)
+        try:
+            with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+                lnl0 = e.log_likelihood()
+                lnl, cg = e.gradient()
+                lnl2, cg2 = e.gradient()
+                assert lnl == lnl0 == lnl2 and np.array_equal(cg, cg2)  # fixed-order reductions in both forms
+                e.set_profiling(True)
+                res[(walk, fuse)] = (lnl, cg, e.pattern_log_likelihoods(), e.profile()["device_bytes"])
+        finally:
+            del os.environ["PHYAMD_WALK"], os.environ["PHYAMD_FUSE"]
+    tol = 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+    for key, (lnl, cg, plk, _) in res.items():
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"]), key
+        assert np.abs(cg - ref["cat_grad"]).max() <= tol, key
+        np.testing.assert_allclose(plk, ref["pattern_lk"], rtol=1e-11, atol=1e-11)
+    assert np.abs(res[(1, 1)][1] - res[(0, 1)][1]).max() <= 1e-11 * max(1.0, np.abs(ref["cat_grad"]).max())
+    if T >= 100 and P >= 2000:
+        assert res[(1, 1)][3] < res[(0, 1)][3]
+
+
 def test_error_behaviour():
     with Engine(4, 10, 4, 2) as e:
         with pytest.raises(EngineError) as ei:
