@@ -252,6 +252,11 @@ class TreeLikelihoodInterface : public CallableModelInterface {
 	                        SubstitutionModelInterface *substitutionModel, SiteModelInterface *siteModel,
 	                        std::optional<BranchModelInterface *> branchModel, bool use_ambiguities = false, bool use_tip_states = false,
 	                        bool include_jacobian = false);
+	// one attribute (state name) per taxon: discrete-trait likelihoods (physher.hpp:369-377, new_AttributePattern)
+	TreeLikelihoodInterface(const std::vector<std::string> &taxa, const std::vector<std::string> &attributes, TreeModelInterface *treeModel,
+	                        SubstitutionModelInterface *substitutionModel, SiteModelInterface *siteModel,
+	                        std::optional<BranchModelInterface *> branchModel, bool use_ambiguities = false, bool use_tip_states = false,
+	                        bool include_jacobian = false);
 	~TreeLikelihoodInterface() override;
 
 	void RequestGradient(std::vector<TreeLikelihoodGradientFlags> flags = std::vector<TreeLikelihoodGradientFlags>());
@@ -269,6 +274,7 @@ class TreeLikelihoodInterface : public CallableModelInterface {
 	const std::vector<unsigned char> &PatternStates() const;  // [taxon][pattern], taxa in alignment order
 
    private:
+	void Init(bool use_tip_states);
 	void Sync();
 	TreeModelInterface *treeModel_;
 	SubstitutionModelInterface *substitutionModel_;

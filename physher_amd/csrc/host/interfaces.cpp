@@ -28,9 +28,18 @@ GeneralDataTypeInterface::GeneralDataTypeInterface(const std::vector<std::string
 	dataType_->state_count = (int)states.size();
 	dataType_->symbol_length = (int)states[0].size();
 	dataType_->states = states;
-	// ambiguity codes of the reference's generic type (datatype.c:212-240) resolve to "unknown" on the tip-state path;
-	// the tip-partial path would need dense tip vectors, which the 4-state engine does not take yet
-	(void)ambiguities;
+	// named ambiguity sets (datatype.c:243-262); exact on the 4-state engine (tip masks), "unknown" on the MFMA engines,
+	// whose tips are one state or all states
+	if (ambiguities.has_value())
+		for (const auto &kv : *ambiguities) {
+			std::vector<int> set;
+			for (const auto &name : kv.second) {
+				auto it = std::find(states.begin(), states.end(), name);
+				if (it == states.end()) throw Error("ambiguity `" + kv.first + "` refers to unknown state `" + name + "`");
+				set.push_back((int)(it - states.begin()));
+			}
+			dataType_->ambiguities.emplace_back(kv.first, set);
+		}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -375,6 +384,7 @@ struct LikelihoodImpl {
 	phyamd_engine *engine = nullptr;
 	Patterns patterns;
 	unsigned long tree_v = ~0ul, subst_v = ~0ul, site_v = ~0ul, clock_v = ~0ul;
+	int S = 0, Sp = 0;  // model states and the engine's (padded) state count
 	unsigned long dq_v = ~0ul;  // substitution-model version the uploaded dQ/dtheta belong to
 	bool dq_rates = false, dq_freqs = false;
 	std::vector<double> branch_lengths, cat_grad;
@@ -388,6 +398,15 @@ static void check(int rc) {
 }
 
 }  // namespace phyamd
+
+// state counts the engine has kernels for; other counts are padded up with states nothing can enter or leave
+static int padded_state_count(int S) {
+	if (S <= 4) return 4;
+	if (S <= 20) return 20;
+	if (S <= 60) return 60;
+	if (S == 61) return 61;
+	throw Error("more than 61 states are not supported by the device engine");
+}
 
 TreeLikelihoodInterface::TreeLikelihoodInterface(const std::vector<std::pair<std::string, std::string>> &alignment, TreeModelInterface *treeModel,
                                                  SubstitutionModelInterface *substitutionModel, SiteModelInterface *siteModel,
@@ -407,28 +426,80 @@ TreeLikelihoodInterface::TreeLikelihoodInterface(const std::vector<std::pair<std
 		seqs.push_back(kv.second);
 	}
 	impl_->patterns = phyamd::compress_patterns(dt, names, seqs);  // new_SitePattern (physher.cpp:569-577)
-	const phyamd::Tree &t = *treeModel->GetTree();
+	Init(use_tip_states);
+}
+
+// new_AttributePattern (sitepattern.c:321-353, physher.cpp:594-629): ONE pattern of weight 1, one attribute (a state name of
+// the data type) per taxon -- discrete-trait / phylogeography likelihoods
+TreeLikelihoodInterface::TreeLikelihoodInterface(const std::vector<std::string> &taxa, const std::vector<std::string> &attributes,
+                                                 TreeModelInterface *treeModel, SubstitutionModelInterface *substitutionModel,
+                                                 SiteModelInterface *siteModel, std::optional<BranchModelInterface *> branchModel, bool use_ambiguities,
+                                                 bool use_tip_states, bool include_jacobian)
+    : treeModel_(treeModel),
+      substitutionModel_(substitutionModel),
+      siteModel_(siteModel),
+      branchModel_(branchModel.has_value() ? *branchModel : nullptr),
+      includeJacobian_(include_jacobian),
+      impl_(std::make_unique<phyamd::LikelihoodImpl>()) {
+	(void)use_ambiguities;
+	if (taxa.size() != attributes.size()) throw Error("taxa and attributes differ in length");
+	const phyamd::DataType &dt = *substitutionModel->GetDataType()->dataType_;
+	phyamd::Patterns &pt = impl_->patterns;
+	pt.taxon_count = (int)taxa.size();
+	pt.pattern_count = pt.site_count = 1;
+	pt.names = taxa;
+	pt.weights.assign(1, 1.0);
+	pt.states.resize(taxa.size());
+	for (size_t i = 0; i < taxa.size(); i++) {
+		const int code = dt.encode_string(attributes[i]);
+		if (code > 255) throw Error("state code does not fit the pattern array");
+		pt.states[i] = (uint8_t)code;
+	}
+	Init(use_tip_states);
+}
+
+void TreeLikelihoodInterface::Init(bool use_tip_states) {
+	const phyamd::DataType &dt = *substitutionModel_->GetDataType()->dataType_;
+	const std::vector<std::string> &names = impl_->patterns.names;
+	const phyamd::Tree &t = *treeModel_->GetTree();
 	if ((int)names.size() != t.tip_count) throw Error("alignment and tree have different numbers of taxa");
 	const int S = dt.state_count, P = impl_->patterns.pattern_count;
-	siteModel->GetModel()->update();
+	if (substitutionModel_->GetModel()->S != S) throw Error("substitution model and data type differ in state count");
+	const int Sp = padded_state_count(S);
+	impl_->S = S;
+	impl_->Sp = Sp;
+	siteModel_->GetModel()->update();
 	phyamd_config cfg{};
 	cfg.tip_count = t.tip_count;
 	cfg.pattern_count = P;
-	cfg.state_count = S;
-	cfg.category_count = siteModel->GetModel()->cat_count;
+	cfg.state_count = Sp;
+	cfg.category_count = siteModel_->GetModel()->cat_count;
 	cfg.device = -1;
 	cfg.rescale = PHYAMD_RESCALE_AUTO;
 	phyamd::check(phyamd_create(&cfg, &impl_->engine));
 	phyamd::check(phyamd_set_topology(impl_->engine, t.left.data(), t.right.data(), t.root));
 	phyamd::check(phyamd_set_pattern_weights(impl_->engine, impl_->patterns.weights.data()));
 	// tlk->mapping: node -> sequence by NAME (treelikelihood.c:1095-1104)
-	std::vector<double> partial((size_t)P * S);
+	std::vector<double> partial((size_t)P * Sp, 0.0), one(S);
+	std::vector<uint8_t> codes_p(P);
+	const bool general_sets = dt.kind == phyamd::DataTypeKind::General && (!dt.ambiguities.empty() || Sp != S);
 	for (int tip = 0; tip < t.tip_count; tip++) {
 		auto it = std::find(names.begin(), names.end(), t.name[tip]);
 		if (it == names.end()) throw Error("Could not find taxon `" + t.name[tip] + "` in alignment");
 		const uint8_t *codes = &impl_->patterns.states[(size_t)(it - names.begin()) * P];
-		if (use_tip_states) phyamd::check(phyamd_set_tip_states(impl_->engine, tip, codes));
-		else {  // "tipstates": false -- datatype->partial per pattern (treelikelihood.c:1106-1117)
+		if (Sp == 4 && (!use_tip_states || general_sets)) {
+			// "tipstates": false -- datatype->partial per pattern (treelikelihood.c:1106-1117); also how ambiguity sets and
+			// padded state spaces reach the 4-state engine (a 0/1 vector becomes the tip's 4-bit mask; padding states stay 0)
+			for (int k = 0; k < P; k++) {
+				dt.partial(codes[k], one.data());
+				for (int i = 0; i < Sp; i++) partial[(size_t)k * Sp + i] = i < S ? one[i] : 0.0;
+			}
+			phyamd::check(phyamd_set_tip_partials(impl_->engine, tip, partial.data()));
+		} else if (use_tip_states || Sp != S || dt.kind == phyamd::DataTypeKind::General) {
+			// codes >= S (unknown, ambiguity sets of wide general types) become "all states" (sitepattern.h:68-82)
+			for (int k = 0; k < P; k++) codes_p[k] = codes[k] >= S ? (uint8_t)Sp : codes[k];
+			phyamd::check(phyamd_set_tip_states(impl_->engine, tip, codes_p.data()));
+		} else {
 			for (int k = 0; k < P; k++) dt.partial(codes[k], &partial[(size_t)k * S]);
 			phyamd::check(phyamd_set_tip_partials(impl_->engine, tip, partial.data()));
 		}
@@ -449,7 +520,7 @@ void TreeLikelihoodInterface::RequestGradient(std::vector<TreeLikelihoodGradient
 	const phyamd::SiteModel &smc = *siteModel_->GetModel();
 	const bool site_params = smc.dist != phyamd::RateDistribution::Constant || smc.has_pinv || smc.has_mu;
 	const phyamd::SubstModel &mc = *substitutionModel_->GetModel();
-	const bool subst_params = mc.S == 4 && mc.name != "JC69";  // m->dPdp != NULL (gtr.c:102, hky.c:72, gensubst.c:189); device side: 4 states
+	const bool subst_params = mc.S == 4 && impl_->Sp == 4 && mc.name != "JC69";  // m->dPdp != NULL (gtr.c:102, hky.c:72, gensubst.c:189); device side: 4 states
 	if (f == 0) {  // TreeLikelihood_initialize_gradient(flags = 0): everything differentiable (treelikelihood.c:255-270)
 		f = (int)TreeLikelihoodGradientFlags::TREE_HEIGHT;
 		if (site_params) f |= (int)TreeLikelihoodGradientFlags::SITE_MODEL;
@@ -502,8 +573,26 @@ void TreeLikelihoodInterface::Sync() {
 	if (I.subst_v != substitutionModel_->version_) {
 		phyamd::SubstModel &m = *substitutionModel_->GetModel();
 		m.update();
-		phyamd::check(phyamd_set_eigen(I.engine, m.eval.data(), m.evec.data(), m.ivec.data()));
-		phyamd::check(phyamd_set_frequencies(I.engine, m.freqs.data()));
+		if (I.Sp == I.S) {
+			phyamd::check(phyamd_set_eigen(I.engine, m.eval.data(), m.evec.data(), m.ivec.data()));
+			phyamd::check(phyamd_set_frequencies(I.engine, m.freqs.data()));
+		} else {
+			// padding states: eigenvalue 0 with unit eigenvectors (P(t) = identity on them), frequency 0, tip partial 0 -- nothing
+			// enters or leaves them and they carry no weight at the root, so lnL and every gradient are those of the S-state model
+			const int S = I.S, Sp = I.Sp;
+			std::vector<double> ev(Sp, 0.0), U((size_t)Sp * Sp, 0.0), Ui((size_t)Sp * Sp, 0.0), f(Sp, 0.0);
+			for (int i = 0; i < Sp; i++) U[(size_t)i * Sp + i] = Ui[(size_t)i * Sp + i] = 1.0;
+			for (int i = 0; i < S; i++) {
+				ev[i] = m.eval[i];
+				f[i] = m.freqs[i];
+				for (int j = 0; j < S; j++) {
+					U[(size_t)i * Sp + j] = m.evec[(size_t)i * S + j];
+					Ui[(size_t)i * Sp + j] = m.ivec[(size_t)i * S + j];
+				}
+			}
+			phyamd::check(phyamd_set_eigen(I.engine, ev.data(), U.data(), Ui.data()));
+			phyamd::check(phyamd_set_frequencies(I.engine, f.data()));
+		}
 		I.subst_v = substitutionModel_->version_;
 	}
 	if (I.site_v != siteModel_->version_) {

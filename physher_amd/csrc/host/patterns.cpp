@@ -66,11 +66,25 @@ int DataType::encode(const char *sym) const {
 	return state_count;
 }
 
+int DataType::encode_string(const std::string &sym) const {
+	if (kind != DataTypeKind::General) return encode(sym.c_str());
+	for (size_t i = 0; i < states.size(); i++)
+		if (states[i] == sym) return (int)i;
+	for (size_t a = 0; a < ambiguities.size(); a++)
+		if (ambiguities[a].first == sym) return state_count + (int)a;
+	return state_count + (int)ambiguities.size();
+}
+
 void DataType::partial(int code, double *out) const {
 	if (kind == DataTypeKind::Nucleotide) {  // datatype.h:26-66
 		static const unsigned char mask[18] = {1, 2, 4, 8, 8, 5, 10, 3, 9, 6, 12, 14, 13, 11, 7, 15, 15, 15};
 		const unsigned m = mask[code < 18 ? code : 17];
 		for (int i = 0; i < 4; i++) out[i] = (m >> i) & 1u ? 1.0 : 0.0;
+		return;
+	}
+	if (kind == DataTypeKind::General && code >= state_count && code - state_count < (int)ambiguities.size()) {  // _generic_partial
+		for (int i = 0; i < state_count; i++) out[i] = 0.0;
+		for (int st : ambiguities[code - state_count].second) out[st] = 1.0;
 		return;
 	}
 	for (int i = 0; i < state_count; i++) out[i] = code >= state_count ? 1.0 : 0.0;

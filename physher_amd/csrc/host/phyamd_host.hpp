@@ -66,7 +66,11 @@ struct DataType {
 	int state_count = 4;
 	int symbol_length = 1;
 	std::vector<std::string> states;  // General
+	// General: named ambiguity sets (GenericDataType_add_ambiguity, datatype.c:243-262): code = state_count + index here,
+	// "unknown" = state_count + ambiguities.size() (datatype.c:184-199)
+	std::vector<std::pair<std::string, std::vector<int>>> ambiguities;
 	int encode(const char *sym) const;                 // datatype.c:55-89, sitepattern.c:796-819
+	int encode_string(const std::string &s) const;     // whole-string lookup (_encoding_string, datatype.c:184-199): attribute patterns
 	void partial(int code, double *out) const;         // ambiguity mask / one-hot / all ones (datatype.h:26-66, datatype.c:212-240)
 };
 

@@ -188,6 +188,11 @@ PYBIND11_MODULE(_phycpp_amd, m) {
 	         py::arg("alignment"), py::arg("tree_model"), py::arg("substitution_model"), py::arg("site_model"), py::arg("branch_model") = py::none(),
 	         py::arg("use_ambiguities") = false, py::arg("use_tip_states") = false, py::arg("include_jacobian") = false, py::keep_alive<1, 3>(),
 	         py::keep_alive<1, 4>(), py::keep_alive<1, 5>(), py::keep_alive<1, 6>())
+	    .def(py::init<const std::vector<std::string> &, const std::vector<std::string> &, TreeModelInterface *, SubstitutionModelInterface *,
+	                  SiteModelInterface *, std::optional<BranchModelInterface *>, bool, bool, bool>(),
+	         py::arg("taxa"), py::arg("attributes"), py::arg("tree_model"), py::arg("substitution_model"), py::arg("site_model"),
+	         py::arg("branch_model") = py::none(), py::arg("use_ambiguities") = false, py::arg("use_tip_states") = false,
+	         py::arg("include_jacobian") = false, py::keep_alive<1, 4>(), py::keep_alive<1, 5>(), py::keep_alive<1, 6>(), py::keep_alive<1, 7>())
 	    .def("request_gradient", &TreeLikelihoodInterface::RequestGradient, py::arg("flags") = std::vector<TreeLikelihoodGradientFlags>())
 	    .def("set_reference_compatibility", &TreeLikelihoodInterface::SetReferenceCompatibility)
 	    .def("get_pattern_count", &TreeLikelihoodInterface::GetPatternCount)

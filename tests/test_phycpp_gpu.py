@@ -271,3 +271,92 @@ def test_site_model_gradient(case):
         fd = (up - dn) / (2 * h)
         assert abs(fd - g[N - 2 + i]) <= 1e-4 * max(1.0, abs(fd)), (i, fd, g[N - 2 + i])
     site.set_parameters(p0)
+
+
+@pytest.mark.parametrize("K,tip_states", [(2, False), (3, True), (4, False), (7, False), (7, True), (20, False), (33, False), (61, True)])
+def test_attribute_patterns_any_state_count(K, tip_states):
+    """The second constructor (taxa + one attribute each, new_AttributePattern): discrete-trait likelihoods with a general
+    data type of K states.  The engine has kernels for 4 / 20 / 60 / 61 states; other K are padded with states nothing can
+    enter or leave.  Checked against the CPU oracle run on the unpadded K-state problem."""
+    from oracle import phyoracle as po
+    from physher_amd import _phycpp_amd as pc, synth
+    rng = np.random.default_rng(40 + K)
+    T = 11
+    tree_s = synth.random_tree(T, rng, bl_low=0.05, bl_high=0.6)
+    names = list(tree_s.names)
+    states = [f"loc{i}" for i in range(K)]
+    tip_codes = rng.integers(0, K, size=T)
+    attrs = [states[c] for c in tip_codes]
+    attrs[3] = "?"  # unknown: all states
+    dt = pc.GeneralDataTypeInterface(states)
+    n_pairs = K * (K - 1) // 2
+    structure = [int(i % 3) for i in range(n_pairs)]
+    rates = [0.7, 1.9, 1.1]
+    freqs = rng.dirichlet(np.full(K, 4.0))
+    subst = pc.GeneralSubstitutionModelInterface(dt, rates, list(freqs), structure, True)
+    site = pc.GammaSiteModelInterface(0.8, 3, None, None)
+    tree = pc.UnRootedTreeModelInterface(tree_s.newick(), names)
+    tlk = pc.TreeLikelihoodInterface(names, attrs, tree, subst, site, None, use_tip_states=tip_states)
+    assert tlk.get_pattern_count() == 1
+    lnl = tlk.log_likelihood()
+    tlk.request_gradient([pc.TreeLikelihoodGradientFlags.TREE_HEIGHT])
+    g = tlk.gradient()
+    # oracle on the K-state problem, node ids / branch lengths as the wrapper's tree has them
+    ev, U, Ui, _ = subst.eigen_system()
+    d = tree.describe()
+    left, right, root, dist = np.array(d["left"]), np.array(d["right"]), d["root"], np.array(d["distance"])
+    dist[root] = 0.0
+    codes = np.array([K if a == "?" else states.index(a) for a in attrs], dtype=np.uint8)
+    order = [names.index(n) for n in d["name"][:T]]
+    pb = po.Problem(left, right, root, np.ones(1), ev, U, Ui, freqs, site.rates(), site.proportions(), dist,
+                    tip_states=codes[order][:, None])
+    ref = pb.gradient()
+    assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+    bg = po.branch_gradient_from_cat(ref["cat_grad"], site.rates(), site.proportions())
+    N = 2 * T - 1
+    rr = right[root]
+    node_map = tree.node_map
+    for i in range(N - 2):  # physher.cpp:649-655: gradient[nodeMap_[i]] = g[i]
+        if i != rr:
+            assert abs(g[node_map[i]] - bg[i]) <= 1e-9 * max(1.0, np.abs(bg).max()), (i, g[node_map[i]], bg[i])
+    p0 = tree.get_parameters()
+    for i in rng.choice(N - 2, size=3, replace=False):  # and it is the derivative of the wrapper's own lnL
+        h = 1e-6
+        pp, pm = p0.copy(), p0.copy()
+        pp[i] += h
+        pm[i] -= h
+        tree.set_parameters(pp)
+        up = tlk.log_likelihood()
+        tree.set_parameters(pm)
+        dn = tlk.log_likelihood()
+        assert abs((up - dn) / (2 * h) - g[i]) <= 2e-5 * max(1.0, abs(g[i]))
+    tree.set_parameters(p0)
+
+
+def test_attribute_patterns_with_ambiguity_sets():
+    """Named ambiguity sets of the general data type (GenericDataType_add_ambiguity, datatype.c:212-262) are exact on the
+    4-state engine: the set becomes the tip's mask."""
+    from oracle import phyoracle as po
+    from physher_amd import _phycpp_amd as pc, synth
+    rng = np.random.default_rng(5)
+    T, K = 9, 3
+    tree_s = synth.random_tree(T, rng, bl_low=0.05, bl_high=0.6)
+    names = list(tree_s.names)
+    states = ["a", "b", "c"]
+    attrs = [states[c] for c in rng.integers(0, K, size=T)]
+    attrs[1], attrs[4], attrs[6] = "ab", "bc", "-"
+    dt = pc.GeneralDataTypeInterface(states, {"ab": ["a", "b"], "bc": ["b", "c"]})
+    subst = pc.GeneralSubstitutionModelInterface(dt, [0.5, 1.5, 1.0], [0.2, 0.5, 0.3], [0, 1, 2], True)
+    site = pc.ConstantSiteModelInterface(None)
+    tree = pc.UnRootedTreeModelInterface(tree_s.newick(), names)
+    tlk = pc.TreeLikelihoodInterface(names, attrs, tree, subst, site, None)
+    ev, U, Ui, _ = subst.eigen_system()
+    d = tree.describe()
+    dist = np.array(d["distance"])
+    dist[d["root"]] = 0.0
+    sets = {"a": [1, 0, 0], "b": [0, 1, 0], "c": [0, 0, 1], "ab": [1, 1, 0], "bc": [0, 1, 1], "-": [1, 1, 1]}
+    tp = np.array([[sets[attrs[names.index(n)]]] for n in d["name"][:T]], dtype=np.float64)  # [T][1][3]
+    pb = po.Problem(d["left"], d["right"], d["root"], np.ones(1), ev, U, Ui, [0.2, 0.5, 0.3], [1.0], [1.0], dist,
+                    tip_states=np.zeros((T, 1), dtype=np.uint8), tip_partials=tp)
+    ref = pb.log_likelihood()
+    assert abs(tlk.log_likelihood() - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
