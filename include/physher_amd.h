@@ -89,6 +89,13 @@ int phyamd_set_topology(phyamd_engine *e, const int32_t *left, const int32_t *ri
  * (treelikelihood.c:1652-1663); the root entry is ignored. */
 int phyamd_set_branch_lengths(phyamd_engine *e, const double *lengths /* [2T-1] */);
 
+/* One branch: Node_set_distance + update_nodes[node] = true (treelikelihood.c:73-92).  The next evaluation recomputes only
+ * the stored partials on the path from `node` to the root (_calculate_partials' dirty walk, treelikelihood.c:1645-1734)
+ * instead of the whole tree; every other setter (and phyamd_set_branch_lengths) implies a full recomputation. */
+int phyamd_set_branch_length(phyamd_engine *e, int node, double length);
+/* SingleTreeLikelihood_update_all_nodes (treelikelihood.c:1737-1771): force the next evaluation to recompute every node. */
+int phyamd_update_all_nodes(phyamd_engine *e);
+
 /* --- models: SubstitutionModel eigen system + frequencies, SiteModel rates/proportions --- */
 /* eval[S], evec[S][S], ivec[S][S]: m->eigendcmp after update_eigen_system (substmodel.c:1092-1115);
  * P(t) = |evec diag(exp(eval t)) ivec| is formed on the device (substmodel.c:518-557). */

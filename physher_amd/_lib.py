@@ -47,6 +47,8 @@ SYMBOLS = [
     ("phyamd_set_pattern_weights", C.c_int, [_P, _P]),
     ("phyamd_set_topology", C.c_int, [_P, _P, _P, C.c_int]),
     ("phyamd_set_branch_lengths", C.c_int, [_P, _P]),
+    ("phyamd_set_branch_length", C.c_int, [_P, C.c_int, C.c_double]),
+    ("phyamd_update_all_nodes", C.c_int, [_P]),
     ("phyamd_set_eigen", C.c_int, [_P, _P, _P, _P]),
     ("phyamd_set_frequencies", C.c_int, [_P, _P]),
     ("phyamd_set_category_rates", C.c_int, [_P, _P, _P]),

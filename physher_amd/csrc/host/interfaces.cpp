@@ -388,6 +388,7 @@ struct LikelihoodImpl {
 	unsigned long dq_v = ~0ul;  // substitution-model version the uploaded dQ/dtheta belong to
 	bool dq_rates = false, dq_freqs = false;
 	std::vector<double> branch_lengths, cat_grad;
+	std::vector<double> sent_lengths;  // what the engine holds
 	~LikelihoodImpl() {
 		if (engine) phyamd_destroy(engine);
 	}
@@ -566,7 +567,18 @@ void TreeLikelihoodInterface::Sync() {
 			} else
 				I.branch_lengths[n] = t.distance[n];
 		}
-		phyamd::check(phyamd_set_branch_lengths(I.engine, I.branch_lengths.data()));
+		// Parameters_set_values only fires listeners for values that changed (update_nodes[index], treelikelihood.c:73-92):
+		// a few changed branches are sent one by one and the engine recomputes only the paths above them
+		size_t diffs = 0;
+		const bool have_prev = I.sent_lengths.size() == I.branch_lengths.size();
+		if (have_prev)
+			for (int n = 0; n < t.node_count; n++) diffs += I.sent_lengths[n] != I.branch_lengths[n];
+		if (have_prev && diffs > 0 && diffs <= (size_t)t.node_count / 4) {
+			for (int n = 0; n < t.node_count; n++)
+				if (I.sent_lengths[n] != I.branch_lengths[n]) phyamd::check(phyamd_set_branch_length(I.engine, n, I.branch_lengths[n]));
+		} else if (!have_prev || diffs > 0)
+			phyamd::check(phyamd_set_branch_lengths(I.engine, I.branch_lengths.data()));
+		I.sent_lengths = I.branch_lengths;
 		I.tree_v = treeModel_->version_;
 		I.clock_v = cv;
 	}

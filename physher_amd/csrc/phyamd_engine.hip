@@ -868,6 +868,16 @@ struct phyamd_engine {
 	int lnl_blocks = 0;    // entries of d_lnl_part the last post-order pass wrote
 	int grad_blocks = 0;   // entries per row of d_gpart the last pre-order pass wrote
 	size_t gpart_row = 0;  // allocated entries per row
+	// incremental (dirty-node) post-order updates: D1, treelikelihood.c:73-114, 1645-1734
+	bool lower_valid = false;         // stored lower partials are those of the current inputs except for `changed` branches
+	bool all_dirty = true;            // something other than single branch lengths changed: recompute every node
+	bool incremental_pass = false;
+	std::vector<int> changed;         // nodes whose branch length changed since the last evaluation
+	std::vector<NodeOp> inc_ops;      // ops of the dirty core nodes, by level
+	std::vector<int> inc_level_off;
+	NodeOp *d_inc_ops = nullptr;
+	const std::vector<int> *act_level_off = nullptr;
+	NodeOp *act_lower_ops = nullptr;
 	bool level_upper_needed = false;  // a level-schedule pre-order pass (parameter gradients) has been requested
 	bool walk_lower_on = true, walk_upper_on = true;  // A/B switches (PHYAMD_WALK_LOWER / PHYAMD_WALK_UPPER = 0)
 	bool walk_enabled = true, walking = false;  // tree-walk kernels (4 states, unscaled, not keep_partials)
@@ -1271,21 +1281,22 @@ dim3 block_dims(const phyamd_engine *e) { return dim3(WAVE, e->C, e->G); }
 
 template <int WAVES, bool SCALE>
 int launch_lower_levels(phyamd_engine *e) {
-	const int levels = (int)e->lower_level_off.size() - 1;
+	const std::vector<int> &level_off = *e->act_level_off;  // all core nodes, or only the dirty ones (incremental update)
+	const int levels = (int)level_off.size() - 1;
 	int launched = 0;
 	const size_t lds = sizeof(double) * ((size_t)4 * e->G * e->C * WAVE + e->G);
 	for (int lv = 0; lv < levels; lv++) {
-		const int off = e->lower_level_off[lv], cnt = e->lower_level_off[lv + 1] - off;
+		const int off = level_off[lv], cnt = level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		const bool is_root = lv == levels - 1;
 		dim3 grid(e->nblk_lower, cnt);
 		launched++;
 		if (is_root)
-			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, true>), grid, block_dims(e), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->C,
+			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, true>), grid, block_dims(e), lds, e->stream, e->act_lower_ops + off, e->T, e->P, e->C,
 			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
 			                   e->d_lnl_part);
 		else
-			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, false>), grid, block_dims(e), SCALE ? lds : 0, e->stream, e->d_lower_ops + off, e->T, e->P,
+			hipLaunchKernelGGL((k_lower4<WAVES, SCALE, false>), grid, block_dims(e), SCALE ? lds : 0, e->stream, e->act_lower_ops + off, e->T, e->P,
 			                   e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
 			                   e->d_lnl_part);
 	}
@@ -1308,7 +1319,7 @@ int launch_lower_walk(phyamd_engine *e) {
 
 template <int WAVES>
 int launch_lower_w(phyamd_engine *e) {
-	if (e->walking && !e->scaling_on && e->walk_lower_on) return launch_lower_walk<WAVES>(e);
+	if (e->walking && !e->scaling_on && e->walk_lower_on && !e->incremental_pass) return launch_lower_walk<WAVES>(e);
 	return e->scaling_on ? launch_lower_levels<WAVES, true>(e) : launch_lower_levels<WAVES, false>(e);
 }
 
@@ -1416,25 +1427,26 @@ int ensure_gen_scale_storage(phyamd_engine *e) {
 
 template <int RT, int KT, bool SCALE>
 int launch_lower_gen(phyamd_engine *e) {
-	const int levels = (int)e->lower_level_off.size() - 1;
+	const std::vector<int> &level_off = *e->act_level_off;
+	const int levels = (int)level_off.size() - 1;
 	const size_t lds = sizeof(double) * 2 * MatImage<RT, KT>::SIZE;
 	int rc;
 	if ((rc = allow_big_lds(k_lower_gen<RT, KT, true, SCALE>, lds)) || (rc = allow_big_lds(k_lower_gen<RT, KT, false, SCALE>, lds))) return rc;
 	if (SCALE && (rc = ensure_gen_scale_storage(e))) return rc;
 	const int pblocks = (e->P + 255) / 256;
 	for (int lv = 0; lv < levels; lv++) {
-		const int off = e->lower_level_off[lv], cnt = e->lower_level_off[lv + 1] - off;
+		const int off = level_off[lv], cnt = level_off[lv + 1] - off;
 		if (cnt == 0) continue;
 		dim3 grid(e->nblk, cnt, e->C);
 		const bool is_root = lv == levels - 1;
 		if (is_root)
-			hipLaunchKernelGGL((k_lower_gen<RT, KT, true, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			hipLaunchKernelGGL((k_lower_gen<RT, KT, true, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->act_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
 			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
 		else
-			hipLaunchKernelGGL((k_lower_gen<RT, KT, false, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
+			hipLaunchKernelGGL((k_lower_gen<RT, KT, false, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->act_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
 			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
 		if (SCALE)
-			hipLaunchKernelGGL(k_scale_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->d_lower_ops + off, e->P, e->Pp, e->S, e->C, e->d_lower, e->d_gen_scratch,
+			hipLaunchKernelGGL(k_scale_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->act_lower_ops + off, e->P, e->Pp, e->S, e->C, e->d_lower, e->d_gen_scratch,
 			                   e->d_lscale, is_root ? e->d_Lc : (double *)nullptr);
 	}
 	const double *lscale_root = SCALE ? e->d_lscale + (size_t)e->core_index[e->root] * e->P : nullptr;
@@ -1511,6 +1523,8 @@ int rebuild_schedule(phyamd_engine *e) {
 	if ((rc = upload_schedule(e))) return rc;
 	if ((rc = ensure_lower_storage(e))) return rc;
 	e->upper_valid = false;
+	e->all_dirty = true;
+	e->lower_valid = false;
 	return PHYAMD_OK;
 }
 
@@ -1527,6 +1541,37 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 	if ((rc = update_matrices(e))) return rc;
 	record(e, 1);
 	if (e->scaling_on && (rc = ensure_scaling_storage(e))) return rc;
+	e->act_level_off = &e->lower_level_off;
+	e->act_lower_ops = e->d_lower_ops;
+	e->incremental_pass = false;
+	if (e->lower_valid && !e->all_dirty) {
+		// only single branch lengths changed since the stored partials were computed: recompute the core nodes on the paths
+		// from those branches to the root, in level order (update_nodes[] semantics, treelikelihood.c:73-114, 1645-1734)
+		if (e->changed.empty()) {  // nothing changed: d_result[0] still holds lnL
+			record(e, 2);
+			e->prof.lower_launches = 0;
+			e->prof_pending = e->profiling;
+			e->prof_with_upper = false;
+			return PHYAMD_OK;
+		}
+		std::vector<uint8_t> dirty(e->N, 0);
+		for (int n : e->changed)
+			for (int a = e->parent[n]; a >= 0 && !dirty[a]; a = e->parent[a])
+				if (e->core_index[a] >= 0) dirty[a] = 1;  // fused fringe nodes are recomputed inside their first stored ancestor
+		e->inc_ops.clear();
+		e->inc_level_off.assign(1, 0);
+		for (size_t lv = 0; lv + 1 < e->lower_level_off.size(); lv++) {
+			for (int i = e->lower_level_off[lv]; i < e->lower_level_off[lv + 1]; i++)
+				if (dirty[e->lower_ops[i].parent]) e->inc_ops.push_back(e->lower_ops[i]);
+			e->inc_level_off.push_back((int)e->inc_ops.size());
+		}
+		if (!e->d_inc_ops && (rc = dev_alloc(e, &e->d_inc_ops, (size_t)e->N))) return rc;
+		HIP_TRY(hipMemcpyAsync(e->d_inc_ops, e->inc_ops.data(), e->inc_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));  // inc_ops is reused by the next call
+		e->act_level_off = &e->inc_level_off;
+		e->act_lower_ops = e->d_inc_ops;
+		e->incremental_pass = true;
+	}
 	for (int attempt = 0; attempt < 2; attempt++) {
 		if ((rc = launch_lower(e))) return rc;
 		hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_lnl_part, e->generic ? e->nblk_root : e->lnl_blocks, (const uint8_t *)nullptr,
@@ -1540,7 +1585,14 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 		e->scaling_on = true;
 		if ((rc = rebuild_schedule(e))) return rc;  // rescaling runs the unfused schedule (every internal node stored)
 		if ((rc = ensure_scaling_storage(e))) return rc;
+		e->act_level_off = &e->lower_level_off;  // and recomputes every node
+		e->act_lower_ops = e->d_lower_ops;
+		e->incremental_pass = false;
 	}
+	e->incremental_pass = false;
+	e->lower_valid = true;
+	e->all_dirty = false;
+	e->changed.clear();
 	record(e, 2);
 	e->prof_pending = e->profiling;
 	e->prof_with_upper = false;
@@ -1795,7 +1847,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	for (void *p : {(void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
-	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops})
+	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops})
 		if (p) (void)hipFree(p);
 	if (e->h_result) (void)hipHostFree(e->h_result);
 	for (auto &ev : e->ev)
@@ -1820,6 +1872,7 @@ int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states) {
 	HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->tip_set[tip] = 1;
+	e->all_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1845,6 +1898,7 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 		HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
 		HIP_TRY(hipStreamSynchronize(e->stream));
 		e->tip_set[tip] = 1;
+		e->all_dirty = true;
 		return PHYAMD_OK;
 	}
 	for (int k = 0; k < e->P; k++) {
@@ -1860,6 +1914,7 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 	HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->tip_set[tip] = 1;
+	e->all_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1871,6 +1926,7 @@ int phyamd_set_pattern_weights(phyamd_engine *e, const double *weights) {
 	HIP_TRY(hipMemcpyAsync(e->d_weights, weights, sizeof(double) * e->P, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_weights = true;
+	e->all_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1910,6 +1966,30 @@ int phyamd_set_branch_lengths(phyamd_engine *e, const double *lengths) {
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_lengths = true;
 	e->matrices_dirty = true;
+	e->all_dirty = true;  // the whole vector: every node is recomputed (SingleTreeLikelihood_update_all_nodes)
+	return PHYAMD_OK;
+}
+
+int phyamd_set_branch_length(phyamd_engine *e, int node, double length) {
+	CHECK_ENGINE(e);
+	if (!e->have_topology || !e->have_lengths) return fail(PHYAMD_EINVAL, "phyamd_set_topology and phyamd_set_branch_lengths come first");
+	if (node < 0 || node >= e->N || node == e->root) return fail(PHYAMD_EINVAL, "node %d has no branch", node);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	if (e->lengths[node] == length) return PHYAMD_OK;
+	e->lengths[node] = length;
+	HIP_TRY(hipMemcpyAsync(e->d_lengths + node, &e->lengths[node], sizeof(double), hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->matrices_dirty = true;  // all P(t) are re-formed (microseconds); only the partials above `node` are recomputed
+	e->changed.push_back(node);
+	e->upper_valid = false;
+	return PHYAMD_OK;
+}
+
+int phyamd_update_all_nodes(phyamd_engine *e) {
+	CHECK_ENGINE(e);
+	e->all_dirty = true;
+	e->matrices_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1940,6 +2020,7 @@ int phyamd_set_eigen(phyamd_engine *e, const double *eval, const double *evec, c
 	e->have_eigen = true;
 	e->matrices_dirty = true;
 	e->params_dirty = true;
+	e->all_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1952,6 +2033,7 @@ int phyamd_set_frequencies(phyamd_engine *e, const double *freqs) {
 	HIP_TRY(hipMemcpyAsync(e->d_freqs, e->freqs.data(), sizeof(double) * e->S, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_freqs = true;
+	e->all_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1967,6 +2049,7 @@ int phyamd_set_category_rates(phyamd_engine *e, const double *rates, const doubl
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_rates = true;
 	e->matrices_dirty = true;
+	e->all_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -1980,6 +2063,9 @@ int phyamd_set_node_matrices(phyamd_engine *e, int node, const double *matrices)
 	e->explicit_host[node] = 1;
 	HIP_TRY(hipMemcpyAsync(e->d_explicit + node, &e->explicit_host[node], 1, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->matrices_dirty = true;  // the tip tables are built from d_mats
+	if (e->have_topology && node != e->root) e->changed.push_back(node);  // like a branch-length change of this one node
+	e->upper_valid = false;
 	return PHYAMD_OK;
 }
 

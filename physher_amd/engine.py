@@ -80,6 +80,13 @@ class Engine:
         assert a.shape == (self.N,)
         self._check(self._lib.phyamd_set_branch_lengths(self._h, _ptr(a)))
 
+    def set_branch_length(self, node, length):
+        """One branch; the next evaluation only recomputes the path from `node` to the root."""
+        self._check(self._lib.phyamd_set_branch_length(self._h, int(node), float(length)))
+
+    def update_all_nodes(self):
+        self._check(self._lib.phyamd_update_all_nodes(self._h))
+
     def set_eigen(self, eval_, evec, ivec):
         a, b, c = _f64(eval_), _f64(evec), _f64(ivec)
         assert a.shape == (self.S,) and b.shape == (self.S, self.S) and c.shape == (self.S, self.S)

@@ -1,0 +1,31 @@
+"""ad-hoc: time of a single-branch incremental update at the cfg5 shape (one GPU)."""
+import sys, time, json
+import numpy as np, torch
+sys.path.insert(0, ".")
+import bench
+from physher_amd import synth
+from physher_amd.engine import Engine, RESCALE_AUTO
+T, P, C = 1000, 1_000_000, 4
+rng = np.random.default_rng(1)
+tree = synth.random_tree(T, rng)
+dev = torch.device("cuda", 0)
+states = bench.evolve_on_device(tree, P, 5, dev, 4).cpu().numpy()
+ev, U, Ui = bench.gtr_eigen()
+rates = np.array(bench.GAMMA4_RATES_05); rates /= rates.mean()
+e = Engine(T, P, 4, C, rescale=RESCALE_AUTO)
+e.set_topology(tree.left, tree.right, tree.root); e.set_branch_lengths(tree.length); e.set_eigen(ev, U, Ui)
+e.set_frequencies(np.array(bench.GTR_FREQS)); e.set_category_rates(rates, np.full(C, 0.25)); e.set_pattern_weights(np.ones(P))
+for t in range(T): e.set_tip_states(t, states[t])
+e.set_profiling(True)
+l0 = e.log_likelihood(); l0 = e.log_likelihood()
+t0 = time.perf_counter(); e.update_all_nodes(); lf = e.log_likelihood(); tfull = time.perf_counter() - t0
+out = {"full_ms": tfull * 1e3, "lnL": lf, "single": []}
+bl = tree.length.copy()
+for n in rng.choice([i for i in range(2 * T - 1) if i != tree.root], size=12, replace=False):
+    bl[n] *= 1.1
+    t0 = time.perf_counter(); e.set_branch_length(int(n), bl[n]); l = e.log_likelihood(); dt = time.perf_counter() - t0
+    out["single"].append({"node": int(n), "ms": dt * 1e3, "launches": e.profile()["lower_launches"], "kernel_ms": e.profile()["lower_ms"]})
+e.update_all_nodes(); lchk = e.log_likelihood()
+out["check_rel"] = abs(l - lchk) / abs(lchk)
+out["median_single_ms"] = float(np.median([s["ms"] for s in out["single"]]))
+print(json.dumps(out))

@@ -272,7 +272,8 @@ def test_tree_walk_kernels_match_level_kernels(T, P, C, shape):
                 lnl0 = e.log_likelihood()
                 lnl, cg = e.gradient()
                 lnl2, cg2 = e.gradient()
-                assert lnl == lnl0 == lnl2 and np.array_equal(cg, cg2)  # fixed-order reductions in both forms
+                assert lnl == lnl2 and np.array_equal(cg, cg2)  # fixed-order reductions in both forms
+                assert abs(lnl - lnl0) <= 1e-13 * abs(lnl)
                 e.set_profiling(True)
                 res[(walk, fuse)] = (lnl, cg, e.pattern_log_likelihoods(), e.profile()["device_bytes"])
         finally:
@@ -544,3 +545,52 @@ def test_parameter_gradient_argument_checks():
     with engine_from_problem(pb20) as e:
         with pytest.raises(EngineError):
             e.set_rate_matrix_derivatives(np.zeros((1, 20, 20)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# D1: incremental (dirty-node) post-order updates
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,T,P,C,rescale", [(4, 60, 700, 4, RESCALE_NEVER), (4, 60, 300, 2, RESCALE_ALWAYS), (20, 25, 90, 2, RESCALE_NEVER),
+                                             (61, 12, 40, 1, RESCALE_ALWAYS)])
+def test_single_branch_updates_recompute_only_the_path_to_the_root(S, T, P, C, rescale):
+    """phyamd_set_branch_length marks one node like update_nodes[] does (treelikelihood.c:73-114): the next evaluation
+    recomputes only the stored nodes above it.  Results equal a full recomputation; the launch count shows the saving."""
+    pb = random_problem(T, P, C, seed=70 + S + T, S=S, gaps=0.03, rescale=1 if rescale == RESCALE_ALWAYS else 0,
+                        bl=(0.3, 0.9) if rescale == RESCALE_ALWAYS else (0.01, 0.1))
+    rng = np.random.default_rng(3)
+    with engine_from_problem(pb, rescale=rescale) as e, engine_from_problem(pb, rescale=rescale) as full:
+        e.set_profiling(True)
+        e.log_likelihood()
+        full_launches = None
+        bl = pb.branch_lengths.copy()
+        for step in range(6):
+            nodes = rng.choice([n for n in range(pb.N) if n != pb.root], size=1 + step % 2, replace=False)
+            for n in nodes:
+                bl[n] *= rng.uniform(0.5, 1.5)
+                e.set_branch_length(int(n), bl[n])
+            lnl = e.log_likelihood()
+            launches = e.profile()["lower_launches"]
+            full.set_branch_lengths(bl)
+            ref = full.log_likelihood()
+            if full_launches is None:
+                full.set_profiling(True)
+                full.set_branch_lengths(bl)
+                full.log_likelihood()
+                full_launches = full.profile()["lower_launches"]
+            assert abs(lnl - ref) <= 1e-12 * abs(ref), (step, lnl, ref)
+            np.testing.assert_allclose(e.pattern_log_likelihoods(), full.pattern_log_likelihoods(), rtol=1e-12, atol=1e-12)
+            assert e.log_likelihood() == lnl and e.profile()["lower_launches"] == 0  # nothing changed: cached
+            # the gradient after an incremental update is the gradient of the current branch lengths
+            if step in (1, 4):
+                l1, cg = e.gradient()
+                l2, cg_ref = full.gradient()
+                assert abs(l1 - l2) <= 1e-12 * abs(l2)
+                assert np.abs(cg - cg_ref).max() <= 1e-10 * max(1.0, np.abs(cg_ref).max())
+        # against the oracle at the final branch lengths
+        pb.branch_lengths[:] = bl
+        orc = pb.log_likelihood()
+        assert abs(e.log_likelihood() - orc["lnl"]) <= 1e-10 * abs(orc["lnl"])
+        # any other setter, or update_all_nodes, falls back to the full pass
+        e.update_all_nodes()
+        assert abs(e.log_likelihood() - orc["lnl"]) <= 1e-10 * abs(orc["lnl"])
+        assert e.profile()["lower_launches"] >= 1
