@@ -65,13 +65,8 @@ constexpr int WAVE = 64;             // lanes per wavefront (gfx950)
 #ifndef PHYAMD_UPPER_MIN_WAVES
 #define PHYAMD_UPPER_MIN_WAVES 6
 #endif
-#ifndef PHYAMD_PPT_WALK
-#define PHYAMD_PPT_WALK 2
-#endif
-#ifndef PHYAMD_PPT_WALK_UPPER
-#define PHYAMD_PPT_WALK_UPPER 4
-#endif
-constexpr int PPT_LOWER = PHYAMD_PPT_LOWER, PPT_UPPER = PHYAMD_PPT_UPPER, PPT_WALK = PHYAMD_PPT_WALK, PPT_WALK_UPPER = PHYAMD_PPT_WALK_UPPER;
+// patterns per thread of the tree-walk kernels are chosen per engine from the shard size (pick_walk_geometry)
+constexpr int PPT_LOWER = PHYAMD_PPT_LOWER, PPT_UPPER = PHYAMD_PPT_UPPER;
 constexpr int MAX_WAVES = 16;        // 1024 threads
 constexpr double SCALING_THRESHOLD = 1.0e-40;  // treelikelihood.c:1121
 
@@ -371,14 +366,14 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict
 
 // ------------------------------------------------------------------------------------------------
 // Tree-walk form of the post-order pass (unscaled evaluations).  Patterns are independent, so instead of one launch
-// per tree level a workgroup keeps its 64*G*PPT_WALK patterns and walks ALL core nodes itself, in depth-first
+// per tree level a workgroup keeps its 64*G*PPT_WALK patterns (PPT_WALK = 1 or 2, by shard size) and walks ALL core nodes itself, in depth-first
 // post-order (larger subtree first).  The op before a node is then always one of its children: that child's partial
 // is taken from registers instead of being read back (it is still stored once for the pre-order pass), and the other
 // child was written by this very thread a short subtree ago, often still in L2 / Infinity Cache.  One launch, no
 // level barriers; the root's integration happens after the loop on the carried root partial.
 // dynamic LDS: G*C*64 doubles (root exchange) + G doubles
 // ------------------------------------------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, int PPT_WALK>
 __global__ __launch_bounds__(WAVES *WAVE) void k_lower4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
                                                              const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
                                                              const double *__restrict__ mats, const double *__restrict__ tiptab,
@@ -711,8 +706,8 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
                                                              double *__restrict__ upper, const double *__restrict__ mats,
                                                              const double *__restrict__ tiptab, const double *__restrict__ Q,
                                                              const double *__restrict__ freqs, const double *__restrict__ w_over_L,
-                                                             double *__restrict__ gpart, int nblk) {
-	extern __shared__ double sh[];  // carried uppers: [PPT_WALK_UPPER][waves][4 components][64 lanes], private to each thread
+                                                             double *__restrict__ gpart, int nblk, int ppt) {
+	extern __shared__ double sh[];  // carried uppers: [ppt][waves][4 components][64 lanes], private to each thread
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const size_t plane = (size_t)P * 4;
 	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
@@ -733,8 +728,8 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 		double *ur_dst = op->upper_slot_right < 0 ? nullptr : upper + ((size_t)op->upper_slot_right * C + c) * plane;
 		Grad4R gr{as_const(Q), FOLD ? one : pi, 0.0, {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.}};
 #pragma unroll 1
-		for (int q = 0; q < PPT_WALK_UPPER; q++) {
-			const int k0 = ((blockIdx.x * PPT_WALK_UPPER + q) * G + g) * WAVE + lane;
+		for (int q = 0; q < ppt; q++) {
+			const int k0 = ((blockIdx.x * ppt + q) * G + g) * WAVE + lane;
 			const bool valid = k0 < P;
 			const int k = valid ? k0 : P - 1;
 			const Ctx4 x{tipmask, mats, tiptab, P, C, c, k};
@@ -865,6 +860,7 @@ struct phyamd_engine {
 	int nblk_root = 0;     // workgroups of k_root_finish (generic)
 	int nblk_lower = 0;    // pattern blocks of the post-order kernels
 	int nblk_walk = 0, nblk_walk_upper = 0;  // pattern blocks of the tree-walk kernels
+	int ppt_walk_lower = 2, ppt_walk_upper = 4;  // their patterns per thread (pick_walk_geometry)
 	int lnl_blocks = 0;    // entries of d_lnl_part the last post-order pass wrote
 	int grad_blocks = 0;   // entries per row of d_gpart the last pre-order pass wrote
 	size_t gpart_row = 0;  // allocated entries per row
@@ -1309,8 +1305,12 @@ int launch_lower_levels(phyamd_engine *e) {
 template <int WAVES>
 int launch_lower_walk(phyamd_engine *e) {
 	const size_t lds = sizeof(double) * ((size_t)e->G * e->C * WAVE + e->G);
-	hipLaunchKernelGGL((k_lower4_walk<WAVES>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(), e->T, e->P,
-	                   e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
+	if (e->ppt_walk_lower == 1)
+		hipLaunchKernelGGL((k_lower4_walk<WAVES, 1>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(), e->T,
+		                   e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
+	else
+		hipLaunchKernelGGL((k_lower4_walk<WAVES, 2>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(), e->T,
+		                   e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
 	HIP_TRY(hipGetLastError());
 	e->prof.lower_launches = 1;
 	e->lnl_blocks = e->nblk_walk;
@@ -1359,13 +1359,13 @@ int launch_upper_levels(phyamd_engine *e, int p0 = 0, int pc = 0) {
 template <int WAVES>
 int launch_upper_walk(phyamd_engine *e, bool fold) {
 	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G;
-	const size_t lds = sizeof(double) * PPT_WALK_UPPER * e->G * e->C * 4 * WAVE;
+	const size_t lds = sizeof(double) * e->ppt_walk_upper * e->G * e->C * 4 * WAVE;
 	if (fold)
 		hipLaunchKernelGGL((k_upper4_walk<WAVES, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C, e->d_tipmask,
-		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
+		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb, e->ppt_walk_upper);
 	else
 		hipLaunchKernelGGL((k_upper4_walk<WAVES, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C, e->d_tipmask,
-		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
+		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb, e->ppt_walk_upper);
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = 1;
 	e->grad_blocks = nb;
@@ -1779,8 +1779,19 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	e->G = std::max(1, 4 / e->C);  // at least 4 waves per workgroup
 	e->nblk = (e->P + WAVE * e->G * PPT_UPPER - 1) / (WAVE * e->G * PPT_UPPER);        // pre-order kernel / gradient slabs
 	e->nblk_lower = (e->P + WAVE * e->G * PPT_LOWER - 1) / (WAVE * e->G * PPT_LOWER);  // post-order kernel / lnL slab
-	e->nblk_walk = (e->P + WAVE * e->G * PPT_WALK - 1) / (WAVE * e->G * PPT_WALK);
-	e->nblk_walk_upper = (e->P + WAVE * e->G * PPT_WALK_UPPER - 1) / (WAVE * e->G * PPT_WALK_UPPER);
+	{
+		// Tree-walk geometry.  More patterns per thread amortise the per-op work (descriptor, matrices, wave reduction) but
+		// leave fewer workgroups: the pre-order walk wants >= ~900 workgroups (it is latency-bound at 4 waves/SIMD), measured
+		// on 125k..1M-pattern shards; the post-order walk is write-bound and prefers one pattern per thread once the shard
+		// fills the chip.  PHYAMD_PPT_WALK_LOWER / PHYAMD_PPT_WALK_UPPER override (A/B runs).
+		const int groups = (e->P + WAVE * e->G - 1) / (WAVE * e->G);  // workgroups at one pattern per thread
+		e->ppt_walk_upper = groups >= 4 * 900 ? 4 : groups >= 2 * 900 ? 2 : 1;
+		e->ppt_walk_lower = groups >= 3000 ? 1 : 2;
+		if (const char *env = std::getenv("PHYAMD_PPT_WALK_LOWER")) e->ppt_walk_lower = std::atoi(env) == 1 ? 1 : 2;
+		if (const char *env = std::getenv("PHYAMD_PPT_WALK_UPPER")) e->ppt_walk_upper = std::max(1, std::min(4, std::atoi(env)));
+		e->nblk_walk = (groups + e->ppt_walk_lower - 1) / e->ppt_walk_lower;
+		e->nblk_walk_upper = (groups + e->ppt_walk_upper - 1) / e->ppt_walk_upper;
+	}
 	if (const char *env = std::getenv("PHYAMD_WALK")) e->walk_enabled = std::atoi(env) != 0;
 	if (const char *env = std::getenv("PHYAMD_WALK_LOWER")) e->walk_lower_on = std::atoi(env) != 0;
 	if (const char *env = std::getenv("PHYAMD_WALK_UPPER")) e->walk_upper_on = std::atoi(env) != 0;
