@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--cpu-sample-patterns", type=int, default=2000)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rescale", choices=("auto", "always", "never"), default="auto",
+                    help="rescaling policy (auto = the reference's lazy switch; always: NOT the headline configuration, measures the rescaled kernels)")
     ap.add_argument("--subst-gradient", action="store_true",
                     help="NOT the headline metric: each step also yields d lnL / d(5 GTR rates, 4 frequencies) (SURVEY 8f.1) in the same two passes")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -200,7 +202,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
 
     from physher_amd import synth
-    from physher_amd.engine import RESCALE_AUTO, Engine
+    from physher_amd.engine import RESCALE_ALWAYS, RESCALE_AUTO, RESCALE_NEVER, Engine
     from physher_amd.sharding import ShardedLikelihood, shard_range
 
     wl = WORKLOADS[args.config]
@@ -241,7 +243,8 @@ def main():
         freqs, ev, U, Ui = reversible_eigen(S, args.seed)
 
     stream = torch.cuda.current_stream(device)
-    eng = Engine(T, Pl, S, C, device=local_rank, rescale=RESCALE_AUTO, stream=stream.cuda_stream)
+    eng = Engine(T, Pl, S, C, device=local_rank, rescale={"auto": RESCALE_AUTO, "always": RESCALE_ALWAYS, "never": RESCALE_NEVER}[args.rescale],
+                 stream=stream.cuda_stream)
     eng.set_topology(tree.left, tree.right, tree.root)
     eng.set_branch_lengths(tree.length)
     eng.set_eigen(ev, U, Ui)
