@@ -65,7 +65,7 @@ constexpr int WAVE = 64;             // lanes per wavefront (gfx950)
 #ifndef PHYAMD_UPPER_MIN_WAVES
 #define PHYAMD_UPPER_MIN_WAVES 6
 #endif
-// patterns per thread of the tree-walk kernels are chosen per engine from the shard size (pick_walk_geometry)
+// patterns per thread of the tree-walk kernels are chosen per engine from the shard size (phyamd_create)
 constexpr int PPT_LOWER = PHYAMD_PPT_LOWER, PPT_UPPER = PHYAMD_PPT_UPPER;
 constexpr int MAX_WAVES = 16;        // 1024 threads
 constexpr double SCALING_THRESHOLD = 1.0e-40;  // treelikelihood.c:1121
@@ -495,17 +495,6 @@ struct Grad4 {
 //   CH_CHERRY     : +0 -> t0, +1 -> t1
 //   CH_CHERRY_TIP : +0 -> t0, +1 -> t1 (inside the inner cherry), +2 -> inner, +3 -> t2
 // Ordered so that few vectors are live at once (the kernel is register-limited).
-// the same accumulators held in registers (tree-walk kernel: reduced and flushed after every op)
-struct Grad4R {
-	cptr Q;
-	d4 f;
-	double wl;
-	double acc[16];
-	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) { acc[i] += wl * dot4(mul4(f, u), matvec4(opaque(Q), b)); }
-	__device__ __forceinline__ void addp_vec(const Ctx4 &, int, const d4 &, const d4 &) {}
-	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) {}
-};
-
 template <bool PARAMS, typename GradT>
 __device__ __forceinline__ void descend_fringe(const Ctx4 &x, GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
                                                const d4 &u) {
@@ -691,71 +680,67 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
 
 // ------------------------------------------------------------------------------------------------
 // Tree-walk form of the pre-order pass + branch gradient (unscaled evaluations), the counterpart of k_lower4_walk: a
-// workgroup keeps its patterns and visits every core node in depth-first pre-order, smaller core subtree first.  The
-// upper partial of the child visited next never leaves registers (no store, no load); the other core child's upper is
-// parked in one of ~log2(core nodes) recycled slots and read back by the same thread after the small subtree.
-// Per op the NACC branch accumulators are reduced over the wave (wave_sum16) and written to the gradient slab:
-// gpart[(node * C + c) * nblk + blockIdx.x * G + g], nblk = gridDim.x * G.
+// workgroup keeps its patterns (ONE per thread) and visits every core node in depth-first pre-order, smaller core subtree
+// first.  The upper partial of the child visited next never leaves registers (no store, no load); the other core child's
+// upper is parked in one of ~log2(core nodes) recycled slots and read back by the same thread after the small subtree.
+// The branch terms of an op go to LDS columns (written once per op) and are reduced over the wave by wave_sum16, then
+// written to the gradient slab: gpart[(node * C + c) * nblk + blockIdx.x * G + g], nblk = gridDim.x * G.
+// Register-lean on purpose (<= 96 VGPRs, 5 waves per SIMD): the walk is bound by dependent latency chains (tip byte ->
+// table gather -> mat-vec, scalar matrix loads), so resident waves matter more than per-op amortisation; a form with 4
+// patterns per thread, carried uppers in LDS and accumulators in registers (126 VGPRs, 4 waves) measured 14 % slower.
+// dynamic LDS: [waves][NACC][64] doubles
 // ------------------------------------------------------------------------------------------------
 #ifndef PHYAMD_WALK_UPPER_MIN_WAVES
-#define PHYAMD_WALK_UPPER_MIN_WAVES 4
+#define PHYAMD_WALK_UPPER_MIN_WAVES 5
 #endif
 template <int WAVES, bool FOLD>
 __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAVES : 1) void k_upper4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
-                                                             const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
-                                                             double *__restrict__ upper, const double *__restrict__ mats,
-                                                             const double *__restrict__ tiptab, const double *__restrict__ Q,
-                                                             const double *__restrict__ freqs, const double *__restrict__ w_over_L,
-                                                             double *__restrict__ gpart, int nblk, int ppt) {
-	extern __shared__ double sh[];  // carried uppers: [ppt][waves][4 components][64 lanes], private to each thread
+                                                              const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
+                                                              double *__restrict__ upper, const double *__restrict__ mats,
+                                                              const double *__restrict__ tiptab, const double *__restrict__ Q,
+                                                              const double *__restrict__ freqs, const double *__restrict__ w_over_L,
+                                                              double *__restrict__ gpart, int nblk) {
+	extern __shared__ double sh[];
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const size_t plane = (size_t)P * 4;
 	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
 	const d4 one = d4{1., 1., 1., 1.};
-	const int nw = G * C, wv = g * C + c;
-	double *my_carry = sh + (size_t)wv * 4 * WAVE + lane;  // + q * nw * 4 * WAVE, component stride WAVE
-	// which accumulator this lane reports after wave_sum16
+	const int wv = g * C + c;
+	double *col = sh + (size_t)wv * NACC * WAVE + lane;  // this thread's NACC slots, stride WAVE
 	const int my = ((lane & 32) ? 8 : 0) + ((lane & 16) ? 4 : 0) + ((lane & 8) ? 2 : 0) + ((lane & 4) ? 1 : 0);
 	const size_t slab = (size_t)blockIdx.x * G + g;
+	const int k0 = (blockIdx.x * G + g) * WAVE + lane;
+	const bool valid = k0 < P;
+	const int k = valid ? k0 : P - 1;
+	const Ctx4 x{tipmask, mats, tiptab, P, C, c, k};
+	const double wl = valid ? w_over_L[k] : 0.0;
+	d4 carry = one;
 #pragma unroll 1
 	for (int i = 0; i < nops; i++) {
 		const NodeOp *op = ops + i;  // wave-uniform: scalar loads
 		const bool proot = i == 0;   // pre-order: the root comes first
 		const int cin = op->carry_in, cout = op->carry_out;
 		const int kl = op->kind_left, kr = op->kind_right;
-		const double *up = (proot || cin) ? nullptr : upper + ((size_t)op->upper_slot_parent * C + c) * plane;
-		double *ul_dst = op->upper_slot_left < 0 ? nullptr : upper + ((size_t)op->upper_slot_left * C + c) * plane;
-		double *ur_dst = op->upper_slot_right < 0 ? nullptr : upper + ((size_t)op->upper_slot_right * C + c) * plane;
-		Grad4R gr{as_const(Q), FOLD ? one : pi, 0.0, {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.}};
-#pragma unroll 1
-		for (int q = 0; q < ppt; q++) {
-			const int k0 = ((blockIdx.x * ppt + q) * G + g) * WAVE + lane;
-			const bool valid = k0 < P;
-			const int k = valid ? k0 : P - 1;
-			const Ctx4 x{tipmask, mats, tiptab, P, C, c, k};
-			double *cq = my_carry + (size_t)q * nw * 4 * WAVE;
-			const d4 bl = child_message(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
-			const d4 br = child_message(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
-			d4 a;
-			if (proot) a = FOLD ? pi : one;
-			else a = matvec4(x.M(op->parent), cin ? d4{cq[0], cq[WAVE], cq[2 * WAVE], cq[3 * WAVE]} : load4(up + (size_t)k * 4));
-			const d4 ul = mul4(a, br), ur = mul4(a, bl);
-			gr.wl = valid ? w_over_L[k] : 0.0;
-			gr.add(0, ul, bl);
-			gr.add(1, ur, br);
-			if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
-			if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
-			if (cout) {  // the next op's parent upper stays on chip
-				const d4 u = cout == 1 ? ul : ur;
-				cq[0] = u.x;
-				cq[WAVE] = u.y;
-				cq[2 * WAVE] = u.z;
-				cq[3 * WAVE] = u.w;
-			}
-			if (kl >= CH_CHERRY) descend_fringe<false>(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul);
-			if (kr >= CH_CHERRY) descend_fringe<false>(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur);
-		}
-		const double tot = wave_sum16(gr.acc, lane);
+#pragma unroll
+		for (int a = 2; a < NACC; a++) col[a * WAVE] = 0.0;  // the fringe slots an op may leave unused
+		Grad4 gr{as_const(Q), FOLD ? one : pi, wl, col, nullptr, nullptr, 0, 0, 0, 0.0};
+		const d4 bl = child_message(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
+		const d4 br = child_message(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
+		d4 a;
+		if (proot) a = FOLD ? pi : one;
+		else a = matvec4(x.M(op->parent), cin ? carry : load4(upper + ((size_t)op->upper_slot_parent * C + c) * plane + (size_t)k * 4));
+		const d4 ul = mul4(a, br), ur = mul4(a, bl);
+		col[0] = wl * dot4(mul4(gr.f, ul), matvec4(opaque(gr.Q), bl));
+		col[WAVE] = wl * dot4(mul4(gr.f, ur), matvec4(opaque(gr.Q), br));
+		if (op->upper_slot_left >= 0 && valid) store4(upper + ((size_t)op->upper_slot_left * C + c) * plane + (size_t)k * 4, ul);
+		if (op->upper_slot_right >= 0 && valid) store4(upper + ((size_t)op->upper_slot_right * C + c) * plane + (size_t)k * 4, ur);
+		carry = cout == 1 ? ul : ur;
+		if (kl >= CH_CHERRY) descend_fringe<false>(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul);
+		if (kr >= CH_CHERRY) descend_fringe<false>(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur);
+		double v[16];
+#pragma unroll
+		for (int a2 = 0; a2 < 16; a2++) v[a2] = a2 < NACC ? col[a2 * WAVE] : 0.0;
+		const double tot = wave_sum16(v, lane);
 		if ((lane & 3) == 0 && my < NACC) {
 			int node = -1;  // accumulator -> gradient row (node id); -1 = unused for this op
 			switch (my) {
@@ -860,7 +845,7 @@ struct phyamd_engine {
 	int nblk_root = 0;     // workgroups of k_root_finish (generic)
 	int nblk_lower = 0;    // pattern blocks of the post-order kernels
 	int nblk_walk = 0, nblk_walk_upper = 0;  // pattern blocks of the tree-walk kernels
-	int ppt_walk_lower = 2, ppt_walk_upper = 4;  // their patterns per thread (pick_walk_geometry)
+	int ppt_walk_lower = 2;  // patterns per thread of the post-order walk
 	int lnl_blocks = 0;    // entries of d_lnl_part the last post-order pass wrote
 	int grad_blocks = 0;   // entries per row of d_gpart the last pre-order pass wrote
 	size_t gpart_row = 0;  // allocated entries per row
@@ -1359,13 +1344,13 @@ int launch_upper_levels(phyamd_engine *e, int p0 = 0, int pc = 0) {
 template <int WAVES>
 int launch_upper_walk(phyamd_engine *e, bool fold) {
 	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G;
-	const size_t lds = sizeof(double) * e->ppt_walk_upper * e->G * e->C * 4 * WAVE;
+	const size_t lds = sizeof(double) * e->G * e->C * NACC * WAVE;
 	if (fold)
-		hipLaunchKernelGGL((k_upper4_walk<WAVES, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C, e->d_tipmask,
-		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb, e->ppt_walk_upper);
+		hipLaunchKernelGGL((k_upper4_walk<WAVES, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
 	else
-		hipLaunchKernelGGL((k_upper4_walk<WAVES, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C, e->d_tipmask,
-		                   e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb, e->ppt_walk_upper);
+		hipLaunchKernelGGL((k_upper4_walk<WAVES, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = 1;
 	e->grad_blocks = nb;
@@ -1780,17 +1765,14 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	e->nblk = (e->P + WAVE * e->G * PPT_UPPER - 1) / (WAVE * e->G * PPT_UPPER);        // pre-order kernel / gradient slabs
 	e->nblk_lower = (e->P + WAVE * e->G * PPT_LOWER - 1) / (WAVE * e->G * PPT_LOWER);  // post-order kernel / lnL slab
 	{
-		// Tree-walk geometry.  More patterns per thread amortise the per-op work (descriptor, matrices, wave reduction) but
-		// leave fewer workgroups: the pre-order walk wants >= ~900 workgroups (it is latency-bound at 4 waves/SIMD), measured
-		// on 125k..1M-pattern shards; the post-order walk is write-bound and prefers one pattern per thread once the shard
-		// fills the chip.  PHYAMD_PPT_WALK_LOWER / PHYAMD_PPT_WALK_UPPER override (A/B runs).
+		// Tree-walk geometry.  The pre-order walk always takes one pattern per thread (see k_upper4_walk); the post-order walk
+		// is write-bound and prefers one pattern per thread once the shard fills the chip, two below that (measured on
+		// 125k..1M-pattern shards).  PHYAMD_PPT_WALK_LOWER overrides (A/B runs).
 		const int groups = (e->P + WAVE * e->G - 1) / (WAVE * e->G);  // workgroups at one pattern per thread
-		e->ppt_walk_upper = groups >= 4 * 900 ? 4 : groups >= 2 * 900 ? 2 : 1;
 		e->ppt_walk_lower = groups >= 3000 ? 1 : 2;
 		if (const char *env = std::getenv("PHYAMD_PPT_WALK_LOWER")) e->ppt_walk_lower = std::atoi(env) == 1 ? 1 : 2;
-		if (const char *env = std::getenv("PHYAMD_PPT_WALK_UPPER")) e->ppt_walk_upper = std::max(1, std::min(4, std::atoi(env)));
 		e->nblk_walk = (groups + e->ppt_walk_lower - 1) / e->ppt_walk_lower;
-		e->nblk_walk_upper = (groups + e->ppt_walk_upper - 1) / e->ppt_walk_upper;
+		e->nblk_walk_upper = groups;
 	}
 	if (const char *env = std::getenv("PHYAMD_WALK")) e->walk_enabled = std::atoi(env) != 0;
 	if (const char *env = std::getenv("PHYAMD_WALK_LOWER")) e->walk_lower_on = std::atoi(env) != 0;
