@@ -495,8 +495,19 @@ struct Grad4 {
 //   CH_CHERRY     : +0 -> t0, +1 -> t1
 //   CH_CHERRY_TIP : +0 -> t0, +1 -> t1 (inside the inner cherry), +2 -> inner, +3 -> t2
 // Ordered so that few vectors are live at once (the kernel is register-limited).
+// tree-walk kernel: one pattern per thread, so every branch term is written exactly once per op (no read-modify-write);
+// Q is diag(pi) Q (or Q when the frequencies are folded into the uppers), so there is no separate state weight
+struct GradW {
+	cptr Q;
+	double wl;
+	double *col;  // this thread's NACC slots in LDS, stride WAVE
+	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const { col[i * WAVE] = wl * dot4(u, matvec4(opaque(Q), b)); }
+	__device__ __forceinline__ void addp_vec(const Ctx4 &, int, const d4 &, const d4 &) const {}
+	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) const {}
+};
+
 template <bool PARAMS, typename GradT>
-__device__ __forceinline__ void descend_fringe(const Ctx4 &x, GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
+__device__ __forceinline__ void descend_fringe(const Ctx4 &x, const GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
                                                const d4 &u) {
 	const d4 b0 = x.tipmsg(t0), b1 = x.tipmsg(t1);
 	d4 a2 = matvec4(x.M(node), u);
@@ -723,15 +734,15 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 		const int kl = op->kind_left, kr = op->kind_right;
 #pragma unroll
 		for (int a = 2; a < NACC; a++) col[a * WAVE] = 0.0;  // the fringe slots an op may leave unused
-		Grad4 gr{as_const(Q), FOLD ? one : pi, wl, col, nullptr, nullptr, 0, 0, 0, 0.0};
+		const GradW gr{as_const(Q), wl, col};  // Q is diag(pi) Q unless FOLD
 		const d4 bl = child_message(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
 		const d4 br = child_message(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
 		d4 a;
 		if (proot) a = FOLD ? pi : one;
 		else a = matvec4(x.M(op->parent), cin ? carry : load4(upper + ((size_t)op->upper_slot_parent * C + c) * plane + (size_t)k * 4));
 		const d4 ul = mul4(a, br), ur = mul4(a, bl);
-		col[0] = wl * dot4(mul4(gr.f, ul), matvec4(opaque(gr.Q), bl));
-		col[WAVE] = wl * dot4(mul4(gr.f, ur), matvec4(opaque(gr.Q), br));
+		gr.add(0, ul, bl);
+		gr.add(1, ur, br);
 		if (op->upper_slot_left >= 0 && valid) store4(upper + ((size_t)op->upper_slot_left * C + c) * plane + (size_t)k * 4, ul);
 		if (op->upper_slot_right >= 0 && valid) store4(upper + ((size_t)op->upper_slot_right * C + c) * plane + (size_t)k * 4, ur);
 		carry = cout == 1 ? ul : ur;
@@ -897,6 +908,9 @@ struct phyamd_engine {
 	uint8_t *d_tipmask = nullptr;
 	double *d_lower = nullptr, *d_upper = nullptr, *d_mats = nullptr, *d_dmats = nullptr;
 	double *d_Q = nullptr;
+	double *d_Qpi = nullptr;          // diag(pi) Q: the tree-walk gradient contracts u with (pi o Q b) in one mat-vec (4 states)
+	std::vector<double> Q_host;
+	bool qpi_dirty = true;
 	bool have_Q = false;
 	double *d_tiptab = nullptr;  // [T][C][16][4] tip messages (4-state)
 	// substitution-parameter gradient (G2)
@@ -1345,12 +1359,22 @@ template <int WAVES>
 int launch_upper_walk(phyamd_engine *e, bool fold) {
 	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G;
 	const size_t lds = sizeof(double) * e->G * e->C * NACC * WAVE;
+	if (e->qpi_dirty) {  // diag(pi) Q, 16 doubles
+		int rc;
+		if (!e->d_Qpi && (rc = dev_alloc(e, &e->d_Qpi, 16))) return rc;
+		double qpi[16];
+		for (int i = 0; i < 4; i++)
+			for (int j = 0; j < 4; j++) qpi[i * 4 + j] = e->freqs[i] * e->Q_host[i * 4 + j];
+		HIP_TRY(hipMemcpyAsync(e->d_Qpi, qpi, sizeof(qpi), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		e->qpi_dirty = false;
+	}
 	if (fold)
 		hipLaunchKernelGGL((k_upper4_walk<WAVES, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
 		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
 	else
 		hipLaunchKernelGGL((k_upper4_walk<WAVES, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
-		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb);
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = 1;
 	e->grad_blocks = nb;
@@ -1840,7 +1864,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	for (void *p : {(void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
-	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops})
+	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops, (void *)e->d_Qpi})
 		if (p) (void)hipFree(p);
 	if (e->h_result) (void)hipHostFree(e->h_result);
 	for (auto &ev : e->ev)
@@ -2006,6 +2030,8 @@ int phyamd_set_eigen(phyamd_engine *e, const double *eval, const double *evec, c
 			Q[(size_t)i * S + j] = q;
 		}
 	HIP_TRY(hipMemcpyAsync(e->d_Q, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, e->stream));
+	e->Q_host = Q;
+	e->qpi_dirty = true;
 	e->have_Q = true;
 	std::fill(e->explicit_host.begin(), e->explicit_host.end(), 0);
 	HIP_TRY(hipMemsetAsync(e->d_explicit, 0, e->N, e->stream));
@@ -2027,6 +2053,7 @@ int phyamd_set_frequencies(phyamd_engine *e, const double *freqs) {
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_freqs = true;
 	e->all_dirty = true;
+	e->qpi_dirty = true;
 	return PHYAMD_OK;
 }
 
@@ -2069,6 +2096,8 @@ int phyamd_set_rate_matrix(phyamd_engine *e, const double *Q) {
 	if ((rc = bind_device(e))) return rc;
 	HIP_TRY(hipMemcpyAsync(e->d_Q, Q, sizeof(double) * e->S * e->S, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->Q_host.assign(Q, Q + (size_t)e->S * e->S);
+	e->qpi_dirty = true;
 	e->have_Q = true;
 	return PHYAMD_OK;
 }
