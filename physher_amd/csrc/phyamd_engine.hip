@@ -671,6 +671,34 @@ __global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER
 	}
 }
 
+// Variants for the pre-order tree walk: the mask bytes of an op's (up to six) tips are all requested at the top of the op,
+// together with the parent's upper, so the op pays one memory round trip for them instead of one per child.
+__device__ __forceinline__ d4 tip_gather(const Ctx4 &x, int t, unsigned m) { return load4(x.tiptab + (((size_t)t * x.C + x.c) * 16 + m) * 4); }
+__device__ __forceinline__ d4 child_message_m(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
+                                              const double *__restrict__ lower, size_t plane, unsigned m0, unsigned m1, unsigned m2) {
+	if (kind == CH_TIP) return tip_gather(x, node, m0);
+	if (kind == CH_CORE) return matvec4(x.M(node), load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4));
+	const d4 cherry = mul4(tip_gather(x, t0, m0), tip_gather(x, t1, m1));
+	if (kind == CH_CHERRY) return matvec4(x.M(node), cherry);
+	return matvec4(x.M(node), mul4(matvec4(x.M(inner), cherry), tip_gather(x, t2, m2)));  // CH_CHERRY_TIP
+}
+template <typename GradT>
+__device__ __forceinline__ void descend_fringe_m(const Ctx4 &x, const GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
+                                                 const d4 &u, unsigned m0, unsigned m1, unsigned m2) {
+	const d4 b0 = tip_gather(x, t0, m0), b1 = tip_gather(x, t1, m1);
+	d4 a2 = matvec4(x.M(node), u);
+	if (kind == CH_CHERRY_TIP) {
+		const d4 bn = matvec4(x.M(inner), mul4(b0, b1));
+		const d4 b2 = tip_gather(x, t2, m2);
+		const d4 un = mul4(a2, b2);
+		gr.add(base + 2, un, bn);
+		gr.add(base + 3, mul4(a2, bn), b2);
+		a2 = matvec4(x.M(inner), un);  // now the upper message entering the inner cherry
+	}
+	gr.add(base + 0, mul4(a2, b1), b0);
+	gr.add(base + 1, mul4(a2, b0), b1);
+}
+
 // sum 16 per-lane values over the 64 lanes of a wave in 17 exchange steps (instead of 16 x 6): after the xor-32 step a
 // lane keeps only half of the values, after xor-16 a quarter, ...  Returns, in every lane, the wave total of value
 // index ((lane >> 2) & 15) with bits taken as (bit5, bit4, bit3, bit2) -> (8, 4, 2, 1).  Fixed order: deterministic.
@@ -735,19 +763,35 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 #pragma unroll
 		for (int a = 2; a < NACC; a++) col[a * WAVE] = 0.0;  // the fringe slots an op may leave unused
 		const GradW gr{as_const(Q), wl, col};  // Q is diag(pi) Q unless FOLD
-		const d4 bl = child_message(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
-		const d4 br = child_message(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
+		// every tip mask byte of the op up front: all in flight together
+		unsigned ml0 = 0, ml1 = 0, ml2 = 0, mr0 = 0, mr1 = 0, mr2 = 0;
+		if (kl == CH_TIP) ml0 = tipmask[(size_t)op->left * P + k];
+		else if (kl >= CH_CHERRY) {
+			ml0 = tipmask[(size_t)op->lt0 * P + k];
+			ml1 = tipmask[(size_t)op->lt1 * P + k];
+			if (kl == CH_CHERRY_TIP) ml2 = tipmask[(size_t)op->lt2 * P + k];
+		}
+		if (kr == CH_TIP) mr0 = tipmask[(size_t)op->right * P + k];
+		else if (kr >= CH_CHERRY) {
+			mr0 = tipmask[(size_t)op->rt0 * P + k];
+			mr1 = tipmask[(size_t)op->rt1 * P + k];
+			if (kr == CH_CHERRY_TIP) mr2 = tipmask[(size_t)op->rt2 * P + k];
+		}
+		d4 uin = carry;  // the parent's upper: carried in registers, or parked by an earlier op of this thread
+		if (!proot && !cin) uin = load4(upper + ((size_t)op->upper_slot_parent * C + c) * plane + (size_t)k * 4);
+		const d4 bl = child_message_m(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane, ml0, ml1, ml2);
+		const d4 br = child_message_m(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane, mr0, mr1, mr2);
 		d4 a;
 		if (proot) a = FOLD ? pi : one;
-		else a = matvec4(x.M(op->parent), cin ? carry : load4(upper + ((size_t)op->upper_slot_parent * C + c) * plane + (size_t)k * 4));
+		else a = matvec4(x.M(op->parent), uin);
 		const d4 ul = mul4(a, br), ur = mul4(a, bl);
 		gr.add(0, ul, bl);
 		gr.add(1, ur, br);
 		if (op->upper_slot_left >= 0 && valid) store4(upper + ((size_t)op->upper_slot_left * C + c) * plane + (size_t)k * 4, ul);
 		if (op->upper_slot_right >= 0 && valid) store4(upper + ((size_t)op->upper_slot_right * C + c) * plane + (size_t)k * 4, ur);
 		carry = cout == 1 ? ul : ur;
-		if (kl >= CH_CHERRY) descend_fringe<false>(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul);
-		if (kr >= CH_CHERRY) descend_fringe<false>(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur);
+		if (kl >= CH_CHERRY) descend_fringe_m(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul, ml0, ml1, ml2);
+		if (kr >= CH_CHERRY) descend_fringe_m(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur, mr0, mr1, mr2);
 		double v[16];
 #pragma unroll
 		for (int a2 = 0; a2 < 16; a2++) v[a2] = a2 < NACC ? col[a2 * WAVE] : 0.0;
