@@ -249,7 +249,7 @@ __global__ void k_parameter_tip_tables(int T, int N, int C, int np, const double
 // HBM.  Wherever its partial is needed it is recomputed from 2-3 tip bytes in registers, and in the pre-order pass
 // its upper partial is pushed down through it in registers, yielding the gradients of its 2-4 inner branches in the
 // same kernel.  Half of the internal nodes of a random tree are of these two shapes, so both passes move about half
-// the bytes.  (Unfused schedules -- rescaling, keep_partials -- run the same kernels with only tip / stored children.)
+// the bytes.  (The unfused schedule of keep_partials runs the same kernels with only tip / stored children.)
 // ------------------------------------------------------------------------------------------------
 // lower: stored partials, array `core` at lower + core * C*P*4, layout [C][P][4] (the reference's)
 // tipmask: [T][P] 4-bit ambiguity masks
@@ -506,6 +506,25 @@ struct GradW {
 	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) const {}
 };
 
+// rescaled evaluations: the branch term is w_k num / D_k with D_k the site likelihood in the op's scaled units; the quotient
+// is formed first (num and D can both be denormal when a category has underflowed)
+struct GradS {
+	cptr Q;
+	d4 f;
+	double w, d;
+	double *acc;
+	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const { acc[i * WAVE] += w * (dot4(mul4(f, u), matvec4(opaque(Q), b)) / d); }
+	__device__ __forceinline__ void addp_vec(const Ctx4 &, int, const d4 &, const d4 &) const {}
+	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) const {}
+};
+// only the substitution-parameter terms of a Grad4 (used next to GradS)
+struct GradPOnly {
+	const Grad4 &g;
+	__device__ __forceinline__ void add(int, const d4 &, const d4 &) const {}
+	__device__ __forceinline__ void addp_vec(const Ctx4 &x, int node, const d4 &u, const d4 &p) const { g.addp_vec(x, node, u, p); }
+	__device__ __forceinline__ void addp_tip(const Ctx4 &x, int tip, const d4 &u) const { g.addp_tip(x, tip, u); }
+};
+
 template <bool PARAMS, typename GradT>
 __device__ __forceinline__ void descend_fringe(const Ctx4 &x, const GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
                                                const d4 &u) {
@@ -592,7 +611,7 @@ __global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER
 			if (op.kind_right >= CH_CHERRY) descend_fringe<PARAMS>(x, gr, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
 			continue;
 		} else {
-			// rescaled (always an unfused schedule): L_k underflows by construction, so the mixture likelihood is re-formed
+			// rescaled: L_k underflows by construction, so the mixture likelihood is re-formed
 			// in this branch's scaled units from all categories' den (exchange through LDS); the scale factors cancel in num / D
 			const double den = dot4(mul4(gr.f, a), mul4(bl, br));
 			const double numl = dot4(mul4(gr.f, ul), matvec4(opaque(gr.Q), bl));
@@ -619,6 +638,18 @@ __global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER
 				else gr.addp_vec(x, op.left, ul, prel);
 				if (op.kind_right == CH_TIP) gr.addp_tip(x, op.right, ur);
 				else gr.addp_vec(x, op.right, ur, prer);
+			}
+			// Fringe children (fused schedules run rescaled too): a cherry or cherry + tip never reaches the rescaling threshold
+			// (products of two or three transition probabilities), so its likelihood is in this op's units and shares D
+			if (op.kind_left >= CH_CHERRY || op.kind_right >= CH_CHERRY) {
+				const GradS gs{gr.Q, gr.f, w, d, gr.acc};
+				if (op.kind_left >= CH_CHERRY) descend_fringe<false>(x, gs, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
+				if (op.kind_right >= CH_CHERRY) descend_fringe<false>(x, gs, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
+				if (PARAMS) {
+					const GradPOnly gp{gr};  // gr.wl = w / D from above
+					if (op.kind_left >= CH_CHERRY) descend_fringe<true>(x, gp, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
+					if (op.kind_right >= CH_CHERRY) descend_fringe<true>(x, gp, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
+				}
 			}
 			// uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
 			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
@@ -1043,9 +1074,10 @@ int build_schedule(phyamd_engine *e) {
 		}
 	}
 	if ((int)order.size() != N) return fail(PHYAMD_EINVAL, "topology is not a single binary tree over all %d nodes", N);
-	// Fringe classification (4-state, unscaled, not keep_partials): cherries (tip, tip) and cherry + tip nodes are fused
+	// Fringe classification (4-state, not keep_partials): cherries (tip, tip) and cherry + tip nodes are fused
 	// into their parent's work and never stored.  Everything else that is internal is a "core" node with an array in HBM.
-	const bool fuse = e->fusion_enabled && !e->generic && !e->keep_partials && !e->scaling_on;
+	// (rescaled evaluations keep the fusion: fringe nodes never reach the rescaling threshold themselves)
+	const bool fuse = e->fusion_enabled && !e->generic && !e->keep_partials;
 	e->fused = fuse;
 	std::vector<int> kind(N, CH_CORE);
 	for (int n = 0; n < T; n++) kind[n] = CH_TIP;
@@ -1636,7 +1668,7 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 		HIP_TRY(hipStreamSynchronize(e->stream));
 		if (!std::isinf(e->h_result[0])) break;
 		e->scaling_on = true;
-		if ((rc = rebuild_schedule(e))) return rc;  // rescaling runs the unfused schedule (every internal node stored)
+		if ((rc = rebuild_schedule(e))) return rc;  // rescaling runs the level kernels (no tree walk), fringe fusion stays
 		if ((rc = ensure_scaling_storage(e))) return rc;
 		e->act_level_off = &e->lower_level_off;  // and recomputes every node
 		e->act_lower_ops = e->d_lower_ops;
@@ -1730,6 +1762,14 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 			return fail(PHYAMD_EINVAL, "PHYAMD_GRAD_FOLD_ROOT_FREQS cannot be combined with parameter gradients (the reference clears include_root_freqs, treelikelihood.c:291-305)");
 	}
 	if ((rc = run_lower(e, true))) return rc;
+	if ((flags & PHYAMD_GRAD_FOLD_ROOT_FREQS) && e->scaling_on && e->fused) {
+		// The reference's folded-frequency arithmetic is inexact for non-uniform pi: under rescaling every
+		// branch then has its own "site likelihood" as denominator, which the fused fringe does not form.  Reproducing it takes
+		// the unfused schedule (every internal node stored) from here on.
+		e->fusion_enabled = false;
+		if ((rc = rebuild_schedule(e))) return rc;
+		if ((rc = run_lower(e, true))) return rc;
+	}
 	if (with_params) e->level_upper_needed = true;
 	if ((rc = ensure_upper_storage(e))) return rc;
 	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
