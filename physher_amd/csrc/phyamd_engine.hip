@@ -460,6 +460,7 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4_walk(const NodeOp *__res
 // dynamic LDS: SCALE: 6 * G*C*64 doubles (three double-buffered exchanges); then NACC * waves * 64 doubles (reduction)
 
 constexpr int NACC = 10;  // gradient accumulators per thread: 2 children + 4 + 4 fringe branches
+constexpr int WCOL = WAVE + 2;  // tree-walk kernel: LDS column stride (padding spreads the quarter-column readers over the banks)
 
 struct Grad4 {
 	cptr Q;
@@ -500,8 +501,8 @@ struct Grad4 {
 struct GradW {
 	cptr Q;
 	double wl;
-	double *col;  // this thread's NACC slots in LDS, stride WAVE
-	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const { col[i * WAVE] = wl * dot4(u, matvec4(opaque(Q), b)); }
+	double *col;  // this thread's NACC slots in LDS, stride WCOL
+	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const { col[i * WCOL] = wl * dot4(u, matvec4(opaque(Q), b)); }
 	__device__ __forceinline__ void addp_vec(const Ctx4 &, int, const d4 &, const d4 &) const {}
 	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) const {}
 };
@@ -706,9 +707,9 @@ __global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER
 // together with the parent's upper, so the op pays one memory round trip for them instead of one per child.
 __device__ __forceinline__ d4 tip_gather(const Ctx4 &x, int t, unsigned m) { return load4(x.tiptab + (((size_t)t * x.C + x.c) * 16 + m) * 4); }
 __device__ __forceinline__ d4 child_message_m(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
-                                              const double *__restrict__ lower, size_t plane, unsigned m0, unsigned m1, unsigned m2) {
+                                              const d4 &pcore, unsigned m0, unsigned m1, unsigned m2) {
 	if (kind == CH_TIP) return tip_gather(x, node, m0);
-	if (kind == CH_CORE) return matvec4(x.M(node), load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4));
+	if (kind == CH_CORE) return matvec4(x.M(node), pcore);
 	const d4 cherry = mul4(tip_gather(x, t0, m0), tip_gather(x, t1, m1));
 	if (kind == CH_CHERRY) return matvec4(x.M(node), cherry);
 	return matvec4(x.M(node), mul4(matvec4(x.M(inner), cherry), tip_gather(x, t2, m2)));  // CH_CHERRY_TIP
@@ -758,7 +759,7 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
 // Register-lean on purpose (<= 96 VGPRs, 5 waves per SIMD): the walk is bound by dependent latency chains (tip byte ->
 // table gather -> mat-vec, scalar matrix loads), so resident waves matter more than per-op amortisation; a form with 4
 // patterns per thread, carried uppers in LDS and accumulators in registers (126 VGPRs, 4 waves) measured 14 % slower.
-// dynamic LDS: [waves][NACC][64] doubles
+// dynamic LDS: [waves][NACC][WCOL] doubles
 // ------------------------------------------------------------------------------------------------
 #ifndef PHYAMD_WALK_UPPER_MIN_WAVES
 #define PHYAMD_WALK_UPPER_MIN_WAVES 5
@@ -776,8 +777,10 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
 	const d4 one = d4{1., 1., 1., 1.};
 	const int wv = g * C + c;
-	double *col = sh + (size_t)wv * NACC * WAVE + lane;  // this thread's NACC slots, stride WAVE
-	const int my = ((lane & 32) ? 8 : 0) + ((lane & 16) ? 4 : 0) + ((lane & 8) ? 2 : 0) + ((lane & 4) ? 1 : 0);
+	double *wave_cols = sh + (size_t)wv * NACC * WCOL;  // this wave's NACC columns of WCOL (= 64 + padding) doubles
+	double *col = wave_cols + lane;                     // this thread's slot in each column, stride WCOL
+	// reduction role of this lane: lanes 0..4*NACC-1 each add a quarter (16 entries) of one column
+	const int my = lane >> 2, seg = lane & 3;
 	const size_t slab = (size_t)blockIdx.x * G + g;
 	const int k0 = (blockIdx.x * G + g) * WAVE + lane;
 	const bool valid = k0 < P;
@@ -791,8 +794,6 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 		const bool proot = i == 0;   // pre-order: the root comes first
 		const int cin = op->carry_in, cout = op->carry_out;
 		const int kl = op->kind_left, kr = op->kind_right;
-#pragma unroll
-		for (int a = 2; a < NACC; a++) col[a * WAVE] = 0.0;  // the fringe slots an op may leave unused
 		const GradW gr{as_const(Q), wl, col};  // Q is diag(pi) Q unless FOLD
 		// every tip mask byte of the op up front: all in flight together
 		unsigned ml0 = 0, ml1 = 0, ml2 = 0, mr0 = 0, mr1 = 0, mr2 = 0;
@@ -810,8 +811,11 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 		}
 		d4 uin = carry;  // the parent's upper: carried in registers, or parked by an earlier op of this thread
 		if (!proot && !cin) uin = load4(upper + ((size_t)op->upper_slot_parent * C + c) * plane + (size_t)k * 4);
-		const d4 bl = child_message_m(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane, ml0, ml1, ml2);
-		const d4 br = child_message_m(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane, mr0, mr1, mr2);
+		d4 pl = one, pr = one;  // stored children
+		if (kl == CH_CORE) pl = load4(lower + ((size_t)op->core_left * C + c) * plane + (size_t)k * 4);
+		if (kr == CH_CORE) pr = load4(lower + ((size_t)op->core_right * C + c) * plane + (size_t)k * 4);
+		const d4 bl = child_message_m(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, pl, ml0, ml1, ml2);
+		const d4 br = child_message_m(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, pr, mr0, mr1, mr2);
 		d4 a;
 		if (proot) a = FOLD ? pi : one;
 		else a = matvec4(x.M(op->parent), uin);
@@ -823,11 +827,20 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 		carry = cout == 1 ? ul : ur;
 		if (kl >= CH_CHERRY) descend_fringe_m(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul, ml0, ml1, ml2);
 		if (kr >= CH_CHERRY) descend_fringe_m(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur, mr0, mr1, mr2);
-		double v[16];
+		// Fixed-order sum of each column over the wave's 64 patterns: four lanes per column add 16 entries each in order,
+		// then (s0 + s1) + (s2 + s3).  Slots an op did not write hold stale values; their rows are never stored.
+		__builtin_amdgcn_wave_barrier();
+		double tot = 0.0;
+		if (my < NACC) {
+			const double *src = wave_cols + my * WCOL + seg * 16;
+			tot = src[0];
 #pragma unroll
-		for (int a2 = 0; a2 < 16; a2++) v[a2] = a2 < NACC ? col[a2 * WAVE] : 0.0;
-		const double tot = wave_sum16(v, lane);
-		if ((lane & 3) == 0 && my < NACC) {
+			for (int j = 1; j < 16; j++) tot += src[j];
+		}
+		tot += __shfl_xor(tot, 1, 64);
+		tot += __shfl_xor(tot, 2, 64);
+		__builtin_amdgcn_wave_barrier();
+		if (seg == 0 && my < NACC) {
 			int node = -1;  // accumulator -> gradient row (node id); -1 = unused for this op
 			switch (my) {
 				case 0: node = op->left; break;
@@ -1434,7 +1447,7 @@ int launch_upper_levels(phyamd_engine *e, int p0 = 0, int pc = 0) {
 template <int WAVES>
 int launch_upper_walk(phyamd_engine *e, bool fold) {
 	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G;
-	const size_t lds = sizeof(double) * e->G * e->C * NACC * WAVE;
+	const size_t lds = sizeof(double) * e->G * e->C * NACC * WCOL;
 	if (e->qpi_dirty) {  // diag(pi) Q, 16 doubles
 		int rc;
 		if (!e->d_Qpi && (rc = dev_alloc(e, &e->d_Qpi, 16))) return rc;
