@@ -497,14 +497,53 @@ struct Grad4 {
 //   CH_CHERRY_TIP : +0 -> t0, +1 -> t1 (inside the inner cherry), +2 -> inner, +3 -> t2
 // Ordered so that few vectors are live at once (the kernel is register-limited).
 // tree-walk kernel: one pattern per thread, so every branch term is written exactly once per op (no read-modify-write);
-// Q is diag(pi) Q (or Q when the frequencies are folded into the uppers), so there is no separate state weight
-struct GradW {
+// Q is diag(pi) Q (or Q when the frequencies are folded into the uppers), so there is no separate state weight.
+// PARAMS: every gradient site also feeds the substitution-parameter gradient, accumulated in the eigen basis:
+//   d lnL / d theta = sum_ab B_theta,ab G_ab,   G_ab = sum_sites w_c F_ab(t r_c) (w_k / L_k) a_a b_b,
+//   a = U^T (pi o u),  b = U^-1 p,  B_theta = U^-1 dQ_theta U,  F as in dPdp_with_dQdp (substmodel.c:469-489)
+// -- 16 accumulators per thread whatever the number of parameters, two extra mat-vecs and 16 multiply-adds per site
+// (the reference walks the tree once per parameter; the level kernels contract with one dP/dtheta per parameter).
+struct ParamCtx {
+	cptr UTpi, Uinv;     // (diag(pi) U)^T and U^-1, 4x4 row-major
+	const double *utab;  // [16][4]: U^-1 . tip mask
+	const double *Fw;    // [N][C][16]: w_c F_ab(t_n r_c)
+};
+template <bool PARAMS>
+struct GradWT {
 	cptr Q;
 	double wl;
 	double *col;  // this thread's NACC slots in LDS, stride WCOL
+	ParamCtx pc;
+	double *G;    // [16], registers of the kernel
 	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const { col[i * WCOL] = wl * dot4(u, matvec4(opaque(Q), b)); }
-	__device__ __forceinline__ void addp_vec(const Ctx4 &, int, const d4 &, const d4 &) const {}
-	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) const {}
+	__device__ __forceinline__ void accumulate(const Ctx4 &x, int node, const d4 &a, const d4 &b) const {
+		const cptr F = opaque(as_const(pc.Fw + ((size_t)node * x.C + x.c) * 16));
+		const double t0 = wl * a.x, t1 = wl * a.y, t2 = wl * a.z, t3 = wl * a.w;
+		G[0] += (F[0] * t0) * b.x;
+		G[1] += (F[1] * t0) * b.y;
+		G[2] += (F[2] * t0) * b.z;
+		G[3] += (F[3] * t0) * b.w;
+		G[4] += (F[4] * t1) * b.x;
+		G[5] += (F[5] * t1) * b.y;
+		G[6] += (F[6] * t1) * b.z;
+		G[7] += (F[7] * t1) * b.w;
+		G[8] += (F[8] * t2) * b.x;
+		G[9] += (F[9] * t2) * b.y;
+		G[10] += (F[10] * t2) * b.z;
+		G[11] += (F[11] * t2) * b.w;
+		G[12] += (F[12] * t3) * b.x;
+		G[13] += (F[13] * t3) * b.y;
+		G[14] += (F[14] * t3) * b.z;
+		G[15] += (F[15] * t3) * b.w;
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	// a branch with a computed lower partial p (stored node, cherry product, ...) / a tip branch with mask m
+	__device__ __forceinline__ void site_vec(const Ctx4 &x, int node, const d4 &u, const d4 &p) const {
+		if (PARAMS) accumulate(x, node, matvec4(opaque(pc.UTpi), u), matvec4(opaque(pc.Uinv), p));
+	}
+	__device__ __forceinline__ void site_tip(const Ctx4 &x, int tip, const d4 &u, unsigned m) const {
+		if (PARAMS) accumulate(x, tip, matvec4(opaque(pc.UTpi), u), load4(pc.utab + m * 4));
+	}
 };
 
 // rescaled evaluations: the branch term is w_k num / D_k with D_k the site likelihood in the op's scaled units; the quotient
@@ -706,13 +745,16 @@ __global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER
 // Variants for the pre-order tree walk: the mask bytes of an op's (up to six) tips are all requested at the top of the op,
 // together with the parent's upper, so the op pays one memory round trip for them instead of one per child.
 __device__ __forceinline__ d4 tip_gather(const Ctx4 &x, int t, unsigned m) { return load4(x.tiptab + (((size_t)t * x.C + x.c) * 16 + m) * 4); }
+// `pre` receives the child's own partial (what the parameter gradient contracts): untouched for tips
 __device__ __forceinline__ d4 child_message_m(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
-                                              const d4 &pcore, unsigned m0, unsigned m1, unsigned m2) {
+                                              const d4 &pcore, unsigned m0, unsigned m1, unsigned m2, d4 &pre) {
 	if (kind == CH_TIP) return tip_gather(x, node, m0);
-	if (kind == CH_CORE) return matvec4(x.M(node), pcore);
-	const d4 cherry = mul4(tip_gather(x, t0, m0), tip_gather(x, t1, m1));
-	if (kind == CH_CHERRY) return matvec4(x.M(node), cherry);
-	return matvec4(x.M(node), mul4(matvec4(x.M(inner), cherry), tip_gather(x, t2, m2)));  // CH_CHERRY_TIP
+	if (kind == CH_CORE) pre = pcore;
+	else {
+		pre = mul4(tip_gather(x, t0, m0), tip_gather(x, t1, m1));                                    // cherry
+		if (kind == CH_CHERRY_TIP) pre = mul4(matvec4(x.M(inner), pre), tip_gather(x, t2, m2));   // cherry + tip
+	}
+	return matvec4(x.M(node), pre);
 }
 template <typename GradT>
 __device__ __forceinline__ void descend_fringe_m(const Ctx4 &x, const GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
@@ -720,15 +762,20 @@ __device__ __forceinline__ void descend_fringe_m(const Ctx4 &x, const GradT &gr,
 	const d4 b0 = tip_gather(x, t0, m0), b1 = tip_gather(x, t1, m1);
 	d4 a2 = matvec4(x.M(node), u);
 	if (kind == CH_CHERRY_TIP) {
-		const d4 bn = matvec4(x.M(inner), mul4(b0, b1));
+		const d4 pn = mul4(b0, b1);
+		const d4 bn = matvec4(x.M(inner), pn);
 		const d4 b2 = tip_gather(x, t2, m2);
 		const d4 un = mul4(a2, b2);
 		gr.add(base + 2, un, bn);
 		gr.add(base + 3, mul4(a2, bn), b2);
+		gr.site_vec(x, inner, un, pn);
+		gr.site_tip(x, t2, mul4(a2, bn), m2);
 		a2 = matvec4(x.M(inner), un);  // now the upper message entering the inner cherry
 	}
 	gr.add(base + 0, mul4(a2, b1), b0);
 	gr.add(base + 1, mul4(a2, b0), b1);
+	gr.site_tip(x, t0, mul4(a2, b1), m0);
+	gr.site_tip(x, t1, mul4(a2, b0), m1);
 }
 
 // sum 16 per-lane values over the 64 lanes of a wave in 17 exchange steps (instead of 16 x 6): after the xor-32 step a
@@ -764,20 +811,24 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
 #ifndef PHYAMD_WALK_UPPER_MIN_WAVES
 #define PHYAMD_WALK_UPPER_MIN_WAVES 5
 #endif
-template <int WAVES, bool FOLD>
-__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAVES : 1) void k_upper4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
+// PARAMS: dynamic LDS holds 16 columns per wave (the eigen-basis sums are reduced once, after the walk); pbuf = [UTpi(16) |
+// Uinv(16) | utab(64)], Fw as in ParamCtx, gacc [16][nblk] receives the per-wave sums.
+template <int WAVES, bool FOLD, bool PARAMS>
+__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : PHYAMD_WALK_UPPER_MIN_WAVES) : 1) void k_upper4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
                                                               const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
                                                               double *__restrict__ upper, const double *__restrict__ mats,
                                                               const double *__restrict__ tiptab, const double *__restrict__ Q,
                                                               const double *__restrict__ freqs, const double *__restrict__ w_over_L,
-                                                              double *__restrict__ gpart, int nblk) {
+                                                              double *__restrict__ gpart, int nblk, const double *__restrict__ pbuf,
+                                                              const double *__restrict__ Fw, double *__restrict__ gacc) {
 	extern __shared__ double sh[];
+	constexpr int NCOL = PARAMS ? 16 : NACC;
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const size_t plane = (size_t)P * 4;
 	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
 	const d4 one = d4{1., 1., 1., 1.};
 	const int wv = g * C + c;
-	double *wave_cols = sh + (size_t)wv * NACC * WCOL;  // this wave's NACC columns of WCOL (= 64 + padding) doubles
+	double *wave_cols = sh + (size_t)wv * NCOL * WCOL;  // this wave's columns of WCOL (= 64 + padding) doubles
 	double *col = wave_cols + lane;                     // this thread's slot in each column, stride WCOL
 	// reduction role of this lane: lanes 0..4*NACC-1 each add a quarter (16 entries) of one column
 	const int my = lane >> 2, seg = lane & 3;
@@ -788,13 +839,15 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 	const Ctx4 x{tipmask, mats, tiptab, P, C, c, k};
 	const double wl = valid ? w_over_L[k] : 0.0;
 	d4 carry = one;
+	double Gab[16] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+	const ParamCtx pc{as_const(pbuf), as_const(pbuf + 16), pbuf + 32, Fw};
 #pragma unroll 1
 	for (int i = 0; i < nops; i++) {
 		const NodeOp *op = ops + i;  // wave-uniform: scalar loads
 		const bool proot = i == 0;   // pre-order: the root comes first
 		const int cin = op->carry_in, cout = op->carry_out;
 		const int kl = op->kind_left, kr = op->kind_right;
-		const GradW gr{as_const(Q), wl, col};  // Q is diag(pi) Q unless FOLD
+		const GradWT<PARAMS> gr{as_const(Q), wl, col, pc, Gab};  // Q is diag(pi) Q unless FOLD
 		// every tip mask byte of the op up front: all in flight together
 		unsigned ml0 = 0, ml1 = 0, ml2 = 0, mr0 = 0, mr1 = 0, mr2 = 0;
 		if (kl == CH_TIP) ml0 = tipmask[(size_t)op->left * P + k];
@@ -814,14 +867,21 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 		d4 pl = one, pr = one;  // stored children
 		if (kl == CH_CORE) pl = load4(lower + ((size_t)op->core_left * C + c) * plane + (size_t)k * 4);
 		if (kr == CH_CORE) pr = load4(lower + ((size_t)op->core_right * C + c) * plane + (size_t)k * 4);
-		const d4 bl = child_message_m(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, pl, ml0, ml1, ml2);
-		const d4 br = child_message_m(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, pr, mr0, mr1, mr2);
+		d4 prel = one, prer = one;  // the children's own partials (the parameter gradient contracts them)
+		const d4 bl = child_message_m(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, pl, ml0, ml1, ml2, prel);
+		const d4 br = child_message_m(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, pr, mr0, mr1, mr2, prer);
 		d4 a;
 		if (proot) a = FOLD ? pi : one;
 		else a = matvec4(x.M(op->parent), uin);
 		const d4 ul = mul4(a, br), ur = mul4(a, bl);
 		gr.add(0, ul, bl);
 		gr.add(1, ur, br);
+		if (PARAMS) {
+			if (kl == CH_TIP) gr.site_tip(x, op->left, ul, ml0);
+			else gr.site_vec(x, op->left, ul, prel);
+			if (kr == CH_TIP) gr.site_tip(x, op->right, ur, mr0);
+			else gr.site_vec(x, op->right, ur, prer);
+		}
 		if (op->upper_slot_left >= 0 && valid) store4(upper + ((size_t)op->upper_slot_left * C + c) * plane + (size_t)k * 4, ul);
 		if (op->upper_slot_right >= 0 && valid) store4(upper + ((size_t)op->upper_slot_right * C + c) * plane + (size_t)k * 4, ur);
 		carry = cout == 1 ? ul : ur;
@@ -857,6 +917,43 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? PHYAMD_WALK_UPPER_MIN_WAV
 			if (node >= 0) gpart[((size_t)node * C + c) * nblk + slab] = tot;
 		}
 	}
+	if (PARAMS) {  // the 16 eigen-basis sums of this wave (all categories add into the same G_ab: one slab entry per wave)
+#pragma unroll
+		for (int a = 0; a < 16; a++) col[a * WCOL] = Gab[a];
+		__builtin_amdgcn_wave_barrier();
+		const double *src = wave_cols + my * WCOL + seg * 16;
+		double tot = src[0];
+#pragma unroll
+		for (int j = 1; j < 16; j++) tot += src[j];
+		tot += __shfl_xor(tot, 1, 64);
+		tot += __shfl_xor(tot, 2, 64);
+		if (seg == 0) gacc[(size_t)my * nblk * C + slab * C + c] = tot;
+	}
+}
+
+// G2 tables of the tree-walk kernel: Fw[n][c][a*4+b] = w_c F_ab(t_n r_c), F_ab = (e^{l_a t} - e^{l_b t}) / (l_a - l_b) or
+// t e^{l_a t} (dPdp_with_dQdp, substmodel.c:469-489); root and explicit-matrix nodes get zeros.  4 states.
+__global__ void k_eigen_weights(int C, int node_count, const double *__restrict__ model, const double *__restrict__ rates,
+                                const double *__restrict__ props, const double *__restrict__ lengths, const uint8_t *__restrict__ is_explicit, int root,
+                                double *__restrict__ Fw) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= node_count * C * 16) return;
+	const int b = idx & 3, a = (idx >> 2) & 3, c = (idx >> 4) % C, n = (idx >> 4) / C;
+	double v = 0.0;
+	if (n != root && !is_explicit[n]) {
+		const double t = lengths[n] * rates[c], la = model[a], lb = model[b], ea = exp(la * t);
+		v = props[c] * (la != lb ? (ea - exp(lb * t)) / (la - lb) : t * ea);
+	}
+	Fw[idx] = v;
+}
+
+// d lnL / d theta = sum_ab B_theta,ab G_ab (B = U^-1 dQ U, [np][16])
+__global__ void k_contract_parameters(int np, const double *__restrict__ B, const double *__restrict__ Gsum, double *__restrict__ out) {
+	const int th = blockIdx.x * blockDim.x + threadIdx.x;
+	if (th >= np) return;
+	double s = 0.0;
+	for (int ab = 0; ab < 16; ab++) s += B[(size_t)th * 16 + ab] * Gsum[ab];
+	out[th] = s;
 }
 
 // fixed-order reduction of per-block slabs: one wave per row. out[row_offset + row] = sum_b part[row][b]
@@ -959,6 +1056,7 @@ struct phyamd_engine {
 	const std::vector<int> *act_level_off = nullptr;
 	NodeOp *act_lower_ops = nullptr;
 	bool level_upper_needed = false;  // a level-schedule pre-order pass (parameter gradients) has been requested
+	bool walk_params_on = true;  // parameter gradients through the tree walk (PHYAMD_WALK_PARAMS = 0: level kernels)
 	bool walk_lower_on = true, walk_upper_on = true;  // A/B switches (PHYAMD_WALK_LOWER / PHYAMD_WALK_UPPER = 0)
 	bool walk_enabled = true, walking = false;  // tree-walk kernels (4 states, unscaled, not keep_partials)
 	std::vector<NodeOp> walk_lower_ops, walk_upper_ops;  // depth-first op orders
@@ -1008,10 +1106,14 @@ struct phyamd_engine {
 	double *d_dpm = nullptr;         // [np][N][C][S][S]
 	double *d_dptab = nullptr;       // [np][T][C][16][4]
 	double *d_ppart = nullptr;       // [np][upper ops][nblk] per-workgroup parameter sums, then [np][upper ops]
+	double *d_Bw = nullptr;          // tree-walk G2: [np][16] U^-1 dQ U
+	double *d_pbuf = nullptr;        // tree-walk G2: [UTpi 16 | Uinv 16 | utab 64]
+	double *d_Fw = nullptr;          // tree-walk G2: [N][C][16] w_c F_ab(t_n r_c)
+	double *d_gacc = nullptr;        // tree-walk G2: [16][slabs * C] per-wave eigen-basis sums, then [16] totals
 	double *d_rf_part = nullptr;     // [S][blocks] partial sums of k_root_frequency_term, then [S]
 	double *d_gen_scratch = nullptr; // rescaled S != 4 path: per-level maxima / numerators / denominators
 	size_t gen_scratch_alloc = 0;
-	size_t np_alloc = 0, ppart_alloc = 0;
+	size_t np_alloc = 0, np_alloc_B = 0, ppart_alloc = 0;
 	bool params_dirty = true;
 	double *d_model = nullptr, *d_freqs = nullptr, *d_rates = nullptr, *d_props = nullptr, *d_lengths = nullptr, *d_weights = nullptr;
 	double *d_wl = nullptr;  // [P] w_k / L_k from the root kernel (unscaled evaluations)
@@ -1444,26 +1546,97 @@ int launch_upper_levels(phyamd_engine *e, int p0 = 0, int pc = 0) {
 	return PHYAMD_OK;
 }
 
+int upload_qpi(phyamd_engine *e) {
+	if (!e->qpi_dirty) return PHYAMD_OK;  // diag(pi) Q, 16 doubles
+	int rc;
+	if (!e->d_Qpi && (rc = dev_alloc(e, &e->d_Qpi, 16))) return rc;
+	double qpi[16];
+	for (int i = 0; i < 4; i++)
+		for (int j = 0; j < 4; j++) qpi[i * 4 + j] = e->freqs[i] * e->Q_host[i * 4 + j];
+	HIP_TRY(hipMemcpyAsync(e->d_Qpi, qpi, sizeof(qpi), hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->qpi_dirty = false;
+	return PHYAMD_OK;
+}
+
 template <int WAVES>
 int launch_upper_walk(phyamd_engine *e, bool fold) {
 	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G;
 	const size_t lds = sizeof(double) * e->G * e->C * NACC * WCOL;
-	if (e->qpi_dirty) {  // diag(pi) Q, 16 doubles
-		int rc;
-		if (!e->d_Qpi && (rc = dev_alloc(e, &e->d_Qpi, 16))) return rc;
-		double qpi[16];
-		for (int i = 0; i < 4; i++)
-			for (int j = 0; j < 4; j++) qpi[i * 4 + j] = e->freqs[i] * e->Q_host[i * 4 + j];
-		HIP_TRY(hipMemcpyAsync(e->d_Qpi, qpi, sizeof(qpi), hipMemcpyHostToDevice, e->stream));
-		HIP_TRY(hipStreamSynchronize(e->stream));
-		e->qpi_dirty = false;
-	}
+	int rc;
+	if ((rc = upload_qpi(e))) return rc;
 	if (fold)
-		hipLaunchKernelGGL((k_upper4_walk<WAVES, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
-		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb);
+		hipLaunchKernelGGL((k_upper4_walk<WAVES, true, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb, (const double *)nullptr,
+		                   (const double *)nullptr, (double *)nullptr);
 	else
-		hipLaunchKernelGGL((k_upper4_walk<WAVES, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
-		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb);
+		hipLaunchKernelGGL((k_upper4_walk<WAVES, false, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
+		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb, (const double *)nullptr,
+		                   (const double *)nullptr, (double *)nullptr);
+	HIP_TRY(hipGetLastError());
+	e->prof.upper_launches = 1;
+	e->grad_blocks = nb;
+	return PHYAMD_OK;
+}
+
+// G2 through the tree walk: B = U^-1 dQ U per parameter, the eigen-basis tables, one walk, then 16 sums and a contraction
+template <int WAVES>
+int launch_upper_walk_params(phyamd_engine *e) {
+	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G, S = 4, np = e->np;
+	const size_t lds = sizeof(double) * e->G * e->C * 16 * WCOL;
+	int rc;
+	if ((rc = upload_qpi(e))) return rc;
+	if ((size_t)np > e->np_alloc_B) {
+		dev_free(e, &e->d_Bw, e->np_alloc_B * 16);
+		e->np_alloc_B = 0;
+		if ((rc = dev_alloc(e, &e->d_Bw, (size_t)np * 16))) return rc;
+		e->np_alloc_B = np;
+	}
+	if (!e->d_pbuf && (rc = dev_alloc(e, &e->d_pbuf, 96))) return rc;
+	if (!e->d_Fw && (rc = dev_alloc(e, &e->d_Fw, (size_t)e->N * e->C * 16))) return rc;
+	if (!e->d_gacc && (rc = dev_alloc(e, &e->d_gacc, (size_t)16 * nb * e->C + 16))) return rc;
+	{
+		const double *evec = e->model.data() + S, *ivec = e->model.data() + S + S * S;
+		std::vector<double> B((size_t)np * 16), tmp(16), pb(96);
+		for (int th = 0; th < np; th++) {
+			const double *dQ = e->dQ_host.data() + (size_t)th * 16;
+			for (int a = 0; a < 4; a++)
+				for (int j = 0; j < 4; j++) {
+					double v = 0.0;
+					for (int i = 0; i < 4; i++) v += ivec[a * 4 + i] * dQ[i * 4 + j];
+					tmp[a * 4 + j] = v;
+				}
+			for (int a = 0; a < 4; a++)
+				for (int b = 0; b < 4; b++) {
+					double v = 0.0;
+					for (int j = 0; j < 4; j++) v += tmp[a * 4 + j] * evec[j * 4 + b];
+					B[(size_t)th * 16 + a * 4 + b] = v;
+				}
+		}
+		for (int a = 0; a < 4; a++)
+			for (int i = 0; i < 4; i++) {
+				pb[a * 4 + i] = evec[i * 4 + a] * e->freqs[i];  // (diag(pi) U)^T
+				pb[16 + a * 4 + i] = ivec[a * 4 + i];
+			}
+		for (int m = 0; m < 16; m++)
+			for (int b = 0; b < 4; b++) {
+				double v = 0.0;
+				for (int j = 0; j < 4; j++)
+					if (m >> j & 1) v += ivec[b * 4 + j];
+				pb[32 + m * 4 + b] = v;  // U^-1 . mask
+			}
+		HIP_TRY(hipMemcpyAsync(e->d_Bw, B.data(), sizeof(double) * B.size(), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipMemcpyAsync(e->d_pbuf, pb.data(), sizeof(double) * pb.size(), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+	}
+	const int nf = e->N * e->C * 16;
+	hipLaunchKernelGGL(k_eigen_weights, dim3((nf + 255) / 256), dim3(256), 0, e->stream, e->C, e->N, e->d_model, e->d_rates, e->d_props, e->d_lengths, e->d_explicit,
+	                   e->root, e->d_Fw);
+	hipLaunchKernelGGL((k_upper4_walk<WAVES, false, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
+	                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb, e->d_pbuf, e->d_Fw, e->d_gacc);
+	double *gsum = e->d_gacc + (size_t)16 * nb * e->C;
+	hipLaunchKernelGGL(k_reduce_rows, dim3(16), dim3(64), 0, e->stream, e->d_gacc, nb * e->C, (const uint8_t *)nullptr, gsum);
+	hipLaunchKernelGGL(k_contract_parameters, dim3(1), dim3(64), 0, e->stream, np, e->d_Bw, gsum, e->d_result + 1 + (size_t)e->N * e->C);
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = 1;
 	e->grad_blocks = nb;
@@ -1783,18 +1956,25 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 		if ((rc = rebuild_schedule(e))) return rc;
 		if ((rc = run_lower(e, true))) return rc;
 	}
-	if (with_params) e->level_upper_needed = true;
+	if (with_params && !(e->walking && !e->scaling_on && e->walk_upper_on && e->walk_params_on)) e->level_upper_needed = true;
 	if ((rc = ensure_upper_storage(e))) return rc;
 	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
 	e->grad_blocks = e->nblk;
-	if (with_params) {
+	const bool walk_params = with_params && e->walking && !e->scaling_on && e->walk_upper_on && e->walk_params_on;
+	if (walk_params) {
+		const int waves = e->C * e->G;
+		rc = waves <= 4 ? launch_upper_walk_params<4>(e) : waves <= 8 ? launch_upper_walk_params<8>(e) : launch_upper_walk_params<16>(e);
+		if (rc) return rc;
+	} else if (with_params) {
 		if ((rc = update_parameter_matrices(e))) return rc;
 		if ((rc = launch_upper_params(e, flags))) return rc;
 	} else if ((rc = launch_upper(e, flags)))
 		return rc;
 	record(e, 3);
 	hipLaunchKernelGGL(k_reduce_rows, dim3(e->N * e->C), dim3(64), 0, e->stream, e->d_gpart, e->grad_blocks, e->d_row_valid, e->d_result + 1);
-	if (with_params) {  // [np][ops][nblk] -> [np][ops] -> [np], fixed order
+	if (walk_params) {
+		if ((rc = launch_root_frequency_term(e, e->d_result + 1 + (size_t)e->N * e->C + e->np))) return rc;
+	} else if (with_params) {  // [np][ops][nblk] -> [np][ops] -> [np], fixed order
 		const int ops = (int)e->upper_ops.size();
 		double *stage = e->d_ppart + (size_t)e->np * ops * e->nblk;
 		hipLaunchKernelGGL(k_reduce_rows, dim3(e->np * ops), dim3(64), 0, e->stream, e->d_ppart, e->nblk, (const uint8_t *)nullptr, stage);
@@ -1898,6 +2078,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if (const char *env = std::getenv("PHYAMD_WALK")) e->walk_enabled = std::atoi(env) != 0;
 	if (const char *env = std::getenv("PHYAMD_WALK_LOWER")) e->walk_lower_on = std::atoi(env) != 0;
 	if (const char *env = std::getenv("PHYAMD_WALK_UPPER")) e->walk_upper_on = std::atoi(env) != 0;
+	if (const char *env = std::getenv("PHYAMD_WALK_PARAMS")) e->walk_params_on = std::atoi(env) != 0;
 	e->generic = e->S != 4;
 	if (e->generic) {
 		e->Pp = (e->P + 15) / 16 * 16;
@@ -1958,7 +2139,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops, (void *)e->d_Qpi})
