@@ -373,16 +373,19 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict
 // level barriers; the root's integration happens after the loop on the carried root partial.
 // dynamic LDS: G*C*64 doubles (root exchange) + G doubles
 // ------------------------------------------------------------------------------------------------
-template <int WAVES, int PPT_WALK>
+template <int WAVES, int PPT_WALK, bool SCALE>
 __global__ __launch_bounds__(WAVES *WAVE) void k_lower4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
                                                              const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
                                                              const double *__restrict__ mats, const double *__restrict__ tiptab,
+                                                             double *__restrict__ lscale,
                                                              const double *__restrict__ freqs, const double *__restrict__ props,
                                                              const double *__restrict__ weights, double *__restrict__ pattern_lk,
                                                              double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
+	// dynamic LDS: root exchange G*C*64 + G doubles; SCALE: + two G*C*64 buffers for the per-op maximum over categories
 	extern __shared__ double sh[];
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
 	const size_t plane = (size_t)P * 4;
+	const int xsz = G * C * WAVE;
 	int kq[PPT_WALK];
 	bool vq[PPT_WALK];
 #pragma unroll
@@ -392,8 +395,13 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4_walk(const NodeOp *__res
 		kq[q] = vq[q] ? k0 : P - 1;
 	}
 	d4 carry[PPT_WALK];
+	double sfc[PPT_WALK];  // SCALE: cumulative log scale factor of the carried partial
 #pragma unroll
-	for (int q = 0; q < PPT_WALK; q++) carry[q] = d4{0., 0., 0., 0.};
+	for (int q = 0; q < PPT_WALK; q++) {
+		carry[q] = d4{0., 0., 0., 0.};
+		sfc[q] = 0.0;
+	}
+	int flip = 0;
 #pragma unroll 1
 	for (int i = 0; i < nops; i++) {
 		const NodeOp *op = ops + i;  // wave-uniform: scalar loads
@@ -406,28 +414,43 @@ __global__ __launch_bounds__(WAVES *WAVE) void k_lower4_walk(const NodeOp *__res
 			                      : child_message(x, op->kind_left, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
 			const d4 b = cin == 2 ? matvec4(x.M(op->right), carry[q])
 			                      : child_message(x, op->kind_right, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
-			const d4 out = mul4(a, b);
+			d4 out = mul4(a, b);
+			if (SCALE) {  // SingleTreeLikelihood_scalePartials (treelikelihood.c:1790-1836): max over categories and states
+				double *xb = sh + xsz + G + (flip & 1) * xsz;
+				flip++;
+				xb[(g * C + c) * WAVE + lane] = max4(out);
+				__syncthreads();
+				double m = 0.0, sf = 0.0;
+				for (int cc = 0; cc < C; cc++) m = fmax(m, xb[(g * C + cc) * WAVE + lane]);
+				if (m < SCALING_THRESHOLD) {
+					out = d4{out.x / m, out.y / m, out.z / m, out.w / m};
+					sf = log(m);
+				}
+				if (op->kind_left == CH_CORE) sf += cin == 1 ? sfc[q] : lscale[(size_t)op->core_left * P + kq[q]];
+				if (op->kind_right == CH_CORE) sf += cin == 2 ? sfc[q] : lscale[(size_t)op->core_right * P + kq[q]];
+				if (c == 0 && vq[q]) lscale[(size_t)op->core_parent * P + kq[q]] = sf;
+				sfc[q] = sf;
+			}
 			if (vq[q]) store4(dst + (size_t)kq[q] * 4, out);
 			carry[q] = out;
 		}
 	}
 	// the last op is the root: integrate_partials + node_log_likelihoods + weighted sum (treelikelihood.c:1473-1487)
 	double acc = 0.0;
-	const int xsz = G * C * WAVE;
 #pragma unroll
 	for (int q = 0; q < PPT_WALK; q++) {
 		const d4 out = carry[q];
-		if (q) __syncthreads();
+		__syncthreads();
 		sh[(g * C + c) * WAVE + lane] = props[c] * (freqs[0] * out.x + freqs[1] * out.y + freqs[2] * out.z + freqs[3] * out.w);
 		__syncthreads();
 		if (c == 0) {
 			double L = 0.0;
 			for (int cc = 0; cc < C; cc++) L += sh[(g * C + cc) * WAVE + lane];
-			const double lk = log(L);
+			const double lk = log(L) + (SCALE ? sfc[q] : 0.0);
 			if (vq[q]) {
 				const double w = weights[kq[q]];
 				pattern_lk[kq[q]] = lk;
-				w_over_L[kq[q]] = w / L;
+				if (!SCALE) w_over_L[kq[q]] = w / L;
 				acc += lk * w;
 			}
 		}
@@ -1291,7 +1314,7 @@ int build_schedule(phyamd_engine *e) {
 	e->upper_slots = e->keep_partials ? N : next_slot;
 
 	// Depth-first op orders for the tree-walk kernels (see k_lower4_walk).  csize = core ops in the subtree.
-	e->walking = e->walk_enabled && !e->generic && !e->keep_partials && !e->scaling_on;
+	e->walking = e->walk_enabled && !e->generic && !e->keep_partials;  // rescaled evaluations: post-order walk only so far
 	e->walk_lower_ops.clear();
 	e->walk_upper_ops.clear();
 	e->walk_upper_slots = 0;
@@ -1414,7 +1437,7 @@ int upload_schedule(phyamd_engine *e) {
 int ensure_upper_storage(phyamd_engine *e) {
 	// the tree-walk schedule parks far fewer uppers than the level schedule keeps; parameter-gradient and inspection
 	// calls still run the level kernels, so the larger of the two is held once either has been needed
-	const bool level_path = !(e->walking && e->walk_upper_on) || e->level_upper_needed;
+	const bool level_path = !(e->walking && e->walk_upper_on && !e->scaling_on) || e->level_upper_needed;
 	const size_t need = (size_t)std::max(1, level_path ? std::max(e->upper_slots, e->walk_upper_slots) : e->walk_upper_slots);
 	if (e->d_upper && e->upper_alloc_slots >= need) return PHYAMD_OK;
 	dev_free(e, &e->d_upper, e->upper_alloc_slots * node_partial_doubles(e));
@@ -1492,15 +1515,17 @@ int launch_lower_levels(phyamd_engine *e) {
 	return PHYAMD_OK;
 }
 
-template <int WAVES>
+template <int WAVES, bool SCALE>
 int launch_lower_walk(phyamd_engine *e) {
-	const size_t lds = sizeof(double) * ((size_t)e->G * e->C * WAVE + e->G);
+	const size_t lds = sizeof(double) * ((size_t)e->G * e->C * WAVE * (SCALE ? 3 : 1) + e->G);
 	if (e->ppt_walk_lower == 1)
-		hipLaunchKernelGGL((k_lower4_walk<WAVES, 1>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(), e->T,
-		                   e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
+		hipLaunchKernelGGL((k_lower4_walk<WAVES, 1, SCALE>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(),
+		                   e->T, e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
+		                   e->d_lnl_part);
 	else
-		hipLaunchKernelGGL((k_lower4_walk<WAVES, 2>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(), e->T,
-		                   e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl, e->d_lnl_part);
+		hipLaunchKernelGGL((k_lower4_walk<WAVES, 2, SCALE>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(),
+		                   e->T, e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
+		                   e->d_lnl_part);
 	HIP_TRY(hipGetLastError());
 	e->prof.lower_launches = 1;
 	e->lnl_blocks = e->nblk_walk;
@@ -1509,7 +1534,7 @@ int launch_lower_walk(phyamd_engine *e) {
 
 template <int WAVES>
 int launch_lower_w(phyamd_engine *e) {
-	if (e->walking && !e->scaling_on && e->walk_lower_on && !e->incremental_pass) return launch_lower_walk<WAVES>(e);
+	if (e->walking && e->walk_lower_on && !e->incremental_pass) return e->scaling_on ? launch_lower_walk<WAVES, true>(e) : launch_lower_walk<WAVES, false>(e);
 	return e->scaling_on ? launch_lower_levels<WAVES, true>(e) : launch_lower_levels<WAVES, false>(e);
 }
 
