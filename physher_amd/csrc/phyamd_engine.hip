@@ -531,14 +531,20 @@ struct ParamCtx {
 	const double *utab;  // [16][4]: U^-1 . tip mask
 	const double *Fw;    // [N][C][16]: w_c F_ab(t_n r_c)
 };
-template <bool PARAMS>
+// SCALE (rescaled evaluations): the branch term is w_k (num / D_k) with D_k the site likelihood in the op's scaled units --
+// quotient first, num and D can both be denormal -- and the parameter sums weight with wl = w_k / D_k.
+template <bool PARAMS, bool SCALE>
 struct GradWT {
 	cptr Q;
 	double wl;
 	double *col;  // this thread's NACC slots in LDS, stride WCOL
 	ParamCtx pc;
 	double *G;    // [16], registers of the kernel
-	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const { col[i * WCOL] = wl * dot4(u, matvec4(opaque(Q), b)); }
+	double w, d;  // SCALE only
+	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const {
+		const double num = dot4(u, matvec4(opaque(Q), b));
+		col[i * WCOL] = SCALE ? w * (num / d) : wl * num;
+	}
 	__device__ __forceinline__ void accumulate(const Ctx4 &x, int node, const d4 &a, const d4 &b) const {
 		const cptr F = opaque(as_const(pc.Fw + ((size_t)node * x.C + x.c) * 16));
 		const double t0 = wl * a.x, t1 = wl * a.y, t2 = wl * a.z, t3 = wl * a.w;
@@ -836,14 +842,17 @@ __device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
 #endif
 // PARAMS: dynamic LDS holds 16 columns per wave (the eigen-basis sums are reduced once, after the walk); pbuf = [UTpi(16) |
 // Uinv(16) | utab(64)], Fw as in ParamCtx, gacc [16][nblk] receives the per-wave sums.
-template <int WAVES, bool FOLD, bool PARAMS>
-__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : PHYAMD_WALK_UPPER_MIN_WAVES) : 1) void k_upper4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
+// SCALE / COMPAT: rescaled evaluations (see k_upper4): one LDS exchange per op gives every category's wave the mixture
+// denominator D_k and the maxima of the two new uppers; dynamic LDS grows by 6 * waves * 64 doubles (double-buffered).
+template <int WAVES, bool FOLD, bool PARAMS, bool SCALE, bool COMPAT>
+__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : (SCALE ? 4 : PHYAMD_WALK_UPPER_MIN_WAVES)) : 1) void k_upper4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
                                                               const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
                                                               double *__restrict__ upper, const double *__restrict__ mats,
                                                               const double *__restrict__ tiptab, const double *__restrict__ Q,
                                                               const double *__restrict__ freqs, const double *__restrict__ w_over_L,
                                                               double *__restrict__ gpart, int nblk, const double *__restrict__ pbuf,
-                                                              const double *__restrict__ Fw, double *__restrict__ gacc) {
+                                                              const double *__restrict__ Fw, double *__restrict__ gacc,
+                                                              const double *__restrict__ props, const double *__restrict__ weights) {
 	extern __shared__ double sh[];
 	constexpr int NCOL = PARAMS ? 16 : NACC;
 	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
@@ -860,7 +869,10 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : PHYAMD_WALK
 	const bool valid = k0 < P;
 	const int k = valid ? k0 : P - 1;
 	const Ctx4 x{tipmask, mats, tiptab, P, C, c, k};
-	const double wl = valid ? w_over_L[k] : 0.0;
+	const double wl = SCALE ? 0.0 : (valid ? w_over_L[k] : 0.0);
+	const double wk = SCALE ? (valid ? weights[k] : 0.0) : 0.0;
+	const int xsz = G * C * WAVE;
+	double *xbase = sh + (size_t)G * C * NCOL * WCOL;  // SCALE: exchange buffers behind the columns
 	d4 carry = one;
 	double Gab[16] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
 	const ParamCtx pc{as_const(pbuf), as_const(pbuf + 16), pbuf + 32, Fw};
@@ -870,7 +882,7 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : PHYAMD_WALK
 		const bool proot = i == 0;   // pre-order: the root comes first
 		const int cin = op->carry_in, cout = op->carry_out;
 		const int kl = op->kind_left, kr = op->kind_right;
-		const GradWT<PARAMS> gr{as_const(Q), wl, col, pc, Gab};  // Q is diag(pi) Q unless FOLD
+		GradWT<PARAMS, SCALE> gr{as_const(Q), wl, col, pc, Gab, 0.0, 1.0};  // Q is diag(pi) Q unless FOLD
 		// every tip mask byte of the op up front: all in flight together
 		unsigned ml0 = 0, ml1 = 0, ml2 = 0, mr0 = 0, mr1 = 0, mr2 = 0;
 		if (kl == CH_TIP) ml0 = tipmask[(size_t)op->left * P + k];
@@ -896,7 +908,28 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : PHYAMD_WALK
 		d4 a;
 		if (proot) a = FOLD ? pi : one;
 		else a = matvec4(x.M(op->parent), uin);
-		const d4 ul = mul4(a, br), ur = mul4(a, bl);
+		d4 ul = mul4(a, br), ur = mul4(a, bl);
+		double ml = 1.0, mr = 1.0;
+		if (SCALE) {
+			// the mixture likelihood in this op's scaled units from all categories (L_k itself underflows by construction)
+			const double den = dot4(FOLD ? a : mul4(pi, a), mul4(bl, br));
+			double *xb = xbase + (size_t)(i & 1) * 3 * xsz;
+			const int xi = wv * WAVE + lane;
+			xb[xi] = props[c] * den;
+			xb[xsz + xi] = max4(ul);
+			xb[2 * xsz + xi] = max4(ur);
+			__syncthreads();
+			double D = 0.0;
+			ml = mr = 0.0;
+			for (int cc = 0; cc < C; cc++) {
+				D += xb[(g * C + cc) * WAVE + lane];
+				ml = fmax(ml, xb[xsz + (g * C + cc) * WAVE + lane]);
+				mr = fmax(mr, xb[2 * xsz + (g * C + cc) * WAVE + lane]);
+			}
+			gr.w = wk;
+			gr.d = COMPAT ? den : D;
+			gr.wl = wk / D;
+		}
 		gr.add(0, ul, bl);
 		gr.add(1, ur, br);
 		if (PARAMS) {
@@ -905,11 +938,16 @@ __global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : PHYAMD_WALK
 			if (kr == CH_TIP) gr.site_tip(x, op->right, ur, mr0);
 			else gr.site_vec(x, op->right, ur, prer);
 		}
+		// fringe children continue in registers with the un-rescaled uppers (they share this op's units and denominator)
+		if (kl >= CH_CHERRY) descend_fringe_m(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul, ml0, ml1, ml2);
+		if (kr >= CH_CHERRY) descend_fringe_m(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur, mr0, mr1, mr2);
+		if (SCALE) {  // uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
+			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
+			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
+		}
 		if (op->upper_slot_left >= 0 && valid) store4(upper + ((size_t)op->upper_slot_left * C + c) * plane + (size_t)k * 4, ul);
 		if (op->upper_slot_right >= 0 && valid) store4(upper + ((size_t)op->upper_slot_right * C + c) * plane + (size_t)k * 4, ur);
 		carry = cout == 1 ? ul : ur;
-		if (kl >= CH_CHERRY) descend_fringe_m(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul, ml0, ml1, ml2);
-		if (kr >= CH_CHERRY) descend_fringe_m(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur, mr0, mr1, mr2);
 		// Fixed-order sum of each column over the wave's 64 patterns: four lanes per column add 16 entries each in order,
 		// then (s0 + s1) + (s2 + s3).  Slots an op did not write hold stale values; their rows are never stored.
 		__builtin_amdgcn_wave_barrier();
@@ -1314,7 +1352,7 @@ int build_schedule(phyamd_engine *e) {
 	e->upper_slots = e->keep_partials ? N : next_slot;
 
 	// Depth-first op orders for the tree-walk kernels (see k_lower4_walk).  csize = core ops in the subtree.
-	e->walking = e->walk_enabled && !e->generic && !e->keep_partials;  // rescaled evaluations: post-order walk only so far
+	e->walking = e->walk_enabled && !e->generic && !e->keep_partials;
 	e->walk_lower_ops.clear();
 	e->walk_upper_ops.clear();
 	e->walk_upper_slots = 0;
@@ -1437,7 +1475,7 @@ int upload_schedule(phyamd_engine *e) {
 int ensure_upper_storage(phyamd_engine *e) {
 	// the tree-walk schedule parks far fewer uppers than the level schedule keeps; parameter-gradient and inspection
 	// calls still run the level kernels, so the larger of the two is held once either has been needed
-	const bool level_path = !(e->walking && e->walk_upper_on && !e->scaling_on) || e->level_upper_needed;
+	const bool level_path = !(e->walking && e->walk_upper_on) || e->level_upper_needed;
 	const size_t need = (size_t)std::max(1, level_path ? std::max(e->upper_slots, e->walk_upper_slots) : e->walk_upper_slots);
 	if (e->d_upper && e->upper_alloc_slots >= need) return PHYAMD_OK;
 	dev_free(e, &e->d_upper, e->upper_alloc_slots * node_partial_doubles(e));
@@ -1584,31 +1622,35 @@ int upload_qpi(phyamd_engine *e) {
 	return PHYAMD_OK;
 }
 
-template <int WAVES>
-int launch_upper_walk(phyamd_engine *e, bool fold) {
+template <int WAVES, bool FOLD, bool SCALE, bool COMPAT>
+int launch_upper_walk_v(phyamd_engine *e) {
 	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G;
-	const size_t lds = sizeof(double) * e->G * e->C * NACC * WCOL;
-	int rc;
-	if ((rc = upload_qpi(e))) return rc;
-	if (fold)
-		hipLaunchKernelGGL((k_upper4_walk<WAVES, true, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
-		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, nb, (const double *)nullptr,
-		                   (const double *)nullptr, (double *)nullptr);
-	else
-		hipLaunchKernelGGL((k_upper4_walk<WAVES, false, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
-		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb, (const double *)nullptr,
-		                   (const double *)nullptr, (double *)nullptr);
+	const size_t lds = sizeof(double) * ((size_t)e->G * e->C * NACC * WCOL + (SCALE ? (size_t)6 * e->G * e->C * WAVE : 0));
+	hipLaunchKernelGGL((k_upper4_walk<WAVES, FOLD, false, SCALE, COMPAT>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T,
+	                   e->P, e->C, e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, FOLD ? e->d_Q : e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb,
+	                   (const double *)nullptr, (const double *)nullptr, (double *)nullptr, e->d_props, e->d_weights);
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = 1;
 	e->grad_blocks = nb;
 	return PHYAMD_OK;
 }
 
-// G2 through the tree walk: B = U^-1 dQ U per parameter, the eigen-basis tables, one walk, then 16 sums and a contraction
 template <int WAVES>
+int launch_upper_walk(phyamd_engine *e, bool fold, bool compat) {
+	int rc;
+	if ((rc = upload_qpi(e))) return rc;
+	if (e->scaling_on) {
+		if (fold) return compat ? launch_upper_walk_v<WAVES, true, true, true>(e) : launch_upper_walk_v<WAVES, true, true, false>(e);
+		return compat ? launch_upper_walk_v<WAVES, false, true, true>(e) : launch_upper_walk_v<WAVES, false, true, false>(e);
+	}
+	return fold ? launch_upper_walk_v<WAVES, true, false, false>(e) : launch_upper_walk_v<WAVES, false, false, false>(e);
+}
+
+// G2 through the tree walk: B = U^-1 dQ U per parameter, the eigen-basis tables, one walk, then 16 sums and a contraction
+template <int WAVES, bool SCALE>
 int launch_upper_walk_params(phyamd_engine *e) {
 	const int ops = (int)e->walk_upper_ops.size(), nb = e->nblk_walk_upper * e->G, S = 4, np = e->np;
-	const size_t lds = sizeof(double) * e->G * e->C * 16 * WCOL;
+	const size_t lds = sizeof(double) * ((size_t)e->G * e->C * 16 * WCOL + (SCALE ? (size_t)6 * e->G * e->C * WAVE : 0));
 	int rc;
 	if ((rc = upload_qpi(e))) return rc;
 	if ((size_t)np > e->np_alloc_B) {
@@ -1657,8 +1699,9 @@ int launch_upper_walk_params(phyamd_engine *e) {
 	const int nf = e->N * e->C * 16;
 	hipLaunchKernelGGL(k_eigen_weights, dim3((nf + 255) / 256), dim3(256), 0, e->stream, e->C, e->N, e->d_model, e->d_rates, e->d_props, e->d_lengths, e->d_explicit,
 	                   e->root, e->d_Fw);
-	hipLaunchKernelGGL((k_upper4_walk<WAVES, false, true>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T, e->P, e->C,
-	                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb, e->d_pbuf, e->d_Fw, e->d_gacc);
+	hipLaunchKernelGGL((k_upper4_walk<WAVES, false, true, SCALE, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T,
+	                   e->P, e->C, e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_tiptab, e->d_Qpi, e->d_freqs, e->d_wl, e->d_gpart, nb, e->d_pbuf, e->d_Fw,
+	                   e->d_gacc, e->d_props, e->d_weights);
 	double *gsum = e->d_gacc + (size_t)16 * nb * e->C;
 	hipLaunchKernelGGL(k_reduce_rows, dim3(16), dim3(64), 0, e->stream, e->d_gacc, nb * e->C, (const uint8_t *)nullptr, gsum);
 	hipLaunchKernelGGL(k_contract_parameters, dim3(1), dim3(64), 0, e->stream, np, e->d_Bw, gsum, e->d_result + 1 + (size_t)e->N * e->C);
@@ -1672,7 +1715,7 @@ template <int WAVES>
 int launch_upper_w(phyamd_engine *e, int flags) {
 	const bool fold = flags & PHYAMD_GRAD_FOLD_ROOT_FREQS, compat = (flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on;
 	e->grad_blocks = e->nblk;
-	if (e->walking && !e->scaling_on && e->walk_upper_on) return launch_upper_walk<WAVES>(e, fold);
+	if (e->walking && e->walk_upper_on) return launch_upper_walk<WAVES>(e, fold, compat);
 	if (e->scaling_on) {
 		if (fold) return compat ? launch_upper_levels<WAVES, true, true, true, false>(e) : launch_upper_levels<WAVES, true, true, false, false>(e);
 		return compat ? launch_upper_levels<WAVES, true, false, true, false>(e) : launch_upper_levels<WAVES, true, false, false, false>(e);
@@ -1981,14 +2024,19 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 		if ((rc = rebuild_schedule(e))) return rc;
 		if ((rc = run_lower(e, true))) return rc;
 	}
-	if (with_params && !(e->walking && !e->scaling_on && e->walk_upper_on && e->walk_params_on)) e->level_upper_needed = true;
+	if (with_params && !(e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on)))
+		e->level_upper_needed = true;
 	if ((rc = ensure_upper_storage(e))) return rc;
 	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
 	e->grad_blocks = e->nblk;
-	const bool walk_params = with_params && e->walking && !e->scaling_on && e->walk_upper_on && e->walk_params_on;
+	// (the compat flag changes only the branch terms; parameter sums always use the mixture denominator: level kernels then)
+	const bool walk_params = with_params && e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on);
 	if (walk_params) {
 		const int waves = e->C * e->G;
-		rc = waves <= 4 ? launch_upper_walk_params<4>(e) : waves <= 8 ? launch_upper_walk_params<8>(e) : launch_upper_walk_params<16>(e);
+		if (e->scaling_on)
+			rc = waves <= 4 ? launch_upper_walk_params<4, true>(e) : waves <= 8 ? launch_upper_walk_params<8, true>(e) : launch_upper_walk_params<16, true>(e);
+		else
+			rc = waves <= 4 ? launch_upper_walk_params<4, false>(e) : waves <= 8 ? launch_upper_walk_params<8, false>(e) : launch_upper_walk_params<16, false>(e);
 		if (rc) return rc;
 	} else if (with_params) {
 		if ((rc = update_parameter_matrices(e))) return rc;
