@@ -87,1004 +87,9 @@ struct NodeOp {
 	int32_t carry_out;  // upper walk: 1 / 2 = the left / right child's upper goes to the next op in registers (not stored)
 };
 
-// ------------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------------
-
-struct d4 {
-	double x, y, z, w;
-};
-
-__device__ __forceinline__ d4 load4(const double *p) {
-	// 32 contiguous bytes per lane: two 16-byte loads (global_load_dwordx4)
-	const double2 a = reinterpret_cast<const double2 *>(p)[0];
-	const double2 b = reinterpret_cast<const double2 *>(p)[1];
-	return d4{a.x, a.y, b.x, b.y};
-}
-
-__device__ __forceinline__ void store4(double *p, const d4 &v) {
-	reinterpret_cast<double2 *>(p)[0] = double2{v.x, v.y};
-	reinterpret_cast<double2 *>(p)[1] = double2{v.z, v.w};
-}
-
-// tip vector from a 4-bit ambiguity mask (one-hot for a known state, 0xF for a gap: datatype.h:26-66)
-__device__ __forceinline__ d4 mask4(unsigned m) {
-	return d4{(m & 1u) ? 1.0 : 0.0, (m & 2u) ? 1.0 : 0.0, (m & 4u) ? 1.0 : 0.0, (m & 8u) ? 1.0 : 0.0};
-}
-
-// Pointer into the AMDGPU constant address space: loads through it with a wave-uniform address become
-// s_load_dwordx* into SGPRs (kernel inputs that no kernel of the same launch writes: matrices, Q, pi, weights).
-typedef const __attribute__((address_space(4))) double *cptr;
-__device__ __forceinline__ cptr as_const(const double *p) { return (cptr)p; }
-
-// y = M v, M row-major 4x4 at a wave-uniform address (scalar loads)
-__device__ __forceinline__ d4 matvec4(cptr M, const d4 &v) {
-	d4 r;
-	r.x = M[0] * v.x + M[1] * v.y + M[2] * v.z + M[3] * v.w;
-	r.y = M[4] * v.x + M[5] * v.y + M[6] * v.z + M[7] * v.w;
-	r.z = M[8] * v.x + M[9] * v.y + M[10] * v.z + M[11] * v.w;
-	r.w = M[12] * v.x + M[13] * v.y + M[14] * v.z + M[15] * v.w;
-	// Fence the scheduler: without it every s_load_dwordx16 of a basic block is hoisted to its top (10 matrices = 320
-	// SGPRs in the fringe paths) and the overflow is parked in VGPR lanes (v_writelane / v_readlane around every use).
-	__builtin_amdgcn_sched_barrier(0);
-	return r;
-}
-
-__device__ __forceinline__ d4 mul4(const d4 &a, const d4 &b) { return d4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
-__device__ __forceinline__ double max4(const d4 &a) { return fmax(fmax(a.x, a.y), fmax(a.z, a.w)); }
-__device__ __forceinline__ double dot4(const d4 &a, const d4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
-// fixed-order sum over the 64 lanes of a wave; every lane ends with the total
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
-}
-
-// Make a wave-uniform pointer opaque to the optimiser.  The matrices are loop-invariant inside the
-// pattern-group loop; without this LLVM hoists all of them out of the loop, runs out of SGPRs and
-// parks them in VGPR lanes (v_writelane/v_readlane pairs around every use).  Re-issuing the scalar
-// loads per group costs a few s_load_dwordx16 from the scalar cache instead.
-__device__ __forceinline__ cptr opaque(cptr p) {
-	asm volatile("" : "+s"(p));
-	return p;
-}
-
-// ------------------------------------------------------------------------------------------------
-// M1/M2: P(t) and dP/dt for every (node, category) from the eigen system (substmodel.c:518-557, 695-723)
-// ------------------------------------------------------------------------------------------------
-// model layout: eval[S] | evec[S*S] | ivec[S*S]
-__global__ void k_transition_matrices(int S, int C, int node_count, const double *__restrict__ model, const double *__restrict__ rates,
-                                      const double *__restrict__ lengths, const uint8_t *__restrict__ is_explicit, int root,
-                                      double *__restrict__ mats, double *__restrict__ dmats) {
-	const size_t total = (size_t)node_count * C * S * S;
-	const double *eval = model, *evec = model + S, *ivec = model + S + S * S;
-	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-		const int j = idx % S;
-		const int i = (idx / S) % S;
-		const int c = (idx / ((size_t)S * S)) % C;
-		const int n = idx / ((size_t)S * S * C);
-		if (n == root || is_explicit[n]) continue;
-		const double t = lengths[n] * rates[c];
-		double p = 0., dp = 0.;
-		for (int k = 0; k < S; k++) {
-			const double e = exp(eval[k] * t);
-			const double w = ivec[k * S + j] * evec[i * S + k];
-			p += w * e;
-			dp += w * (eval[k] * e);
-		}
-		mats[idx] = fabs(p);  // substmodel.c:552
-		dmats[idx] = dp;
-	}
-}
-
-// Tip messages, 4 states: for every (tip, category) the 16 vectors  P(t) . mask  (mask = 4-bit ambiguity code) are
-// tabulated once per evaluation, so "transition matrix times tip vector" is one 32-byte gather per (tip, pattern)
-// instead of 16 multiply-adds: tiptab[tip][c][mask][i] = sum_j P[i][j] bit_j(mask).  2 MB at 1000 taxa x 4 categories.
-__global__ void k_tip_tables(int T, int C, const double *__restrict__ mats, double *__restrict__ tiptab) {
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= T * C * 64) return;
-	const int i = idx & 3, m = (idx >> 2) & 15, tc = idx >> 6;  // tc = tip * C + c
-	const double *M = mats + (size_t)tc * 16 + i * 4;
-	double s = 0.0;
-	if (m & 1) s += M[0];
-	if (m & 2) s += M[1];
-	if (m & 4) s += M[2];
-	if (m & 8) s += M[3];
-	tiptab[idx] = s;
-}
-
-// G2: dP/dtheta for every (parameter, node, category) from B_theta = U^-1 (dQ/dtheta) U:
-//   dP = U ( B o F(t) ) U^-1,  F_ab = (e^{l_a t} - e^{l_b t}) / (l_a - l_b)  or  t e^{l_a t} when l_a == l_b
-// (dPdp_with_dQdp, substmodel.c:469-489).  dpm: [NP][N][C][S][S]; root and explicit-matrix nodes get zeros.
-__global__ void k_parameter_matrices(int S, int C, int node_count, int np, const double *__restrict__ model, const double *__restrict__ B,
-                                     const double *__restrict__ rates, const double *__restrict__ lengths,
-                                     const uint8_t *__restrict__ is_explicit, int root, double *__restrict__ dpm) {
-	const size_t per = (size_t)node_count * C * S * S, total = per * np;
-	const double *eval = model, *evec = model + S, *ivec = model + S + S * S;
-	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-		const int j = idx % S;
-		const int i = (idx / S) % S;
-		const int c = (idx / ((size_t)S * S)) % C;
-		const int n = (idx / ((size_t)S * S * C)) % node_count;
-		const int th = idx / per;
-		double v = 0.0;
-		if (n != root && !is_explicit[n]) {
-			const double t = lengths[n] * rates[c];
-			const double *Bt = B + (size_t)th * S * S;
-			for (int a = 0; a < S; a++) {
-				const double ea = exp(eval[a] * t);
-				double row = 0.0;
-				for (int b = 0; b < S; b++) {
-					const double f = eval[a] != eval[b] ? (ea - exp(eval[b] * t)) / (eval[a] - eval[b]) : t * ea;
-					row += Bt[a * S + b] * f * ivec[b * S + j];
-				}
-				v += evec[i * S + a] * row;
-			}
-		}
-		dpm[idx] = v;
-	}
-}
-
-// tip tables of dP/dtheta, like k_tip_tables: dptab[th][tip][c][mask][i] = sum_j dP_th[tip][c][i][j] bit_j(mask)
-__global__ void k_parameter_tip_tables(int T, int N, int C, int np, const double *__restrict__ dpm, double *__restrict__ dptab) {
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= np * T * C * 64) return;
-	const int i = idx & 3, m = (idx >> 2) & 15, tc = (idx >> 6) % (T * C), th = (idx >> 6) / (T * C);
-	const double *M = dpm + ((size_t)th * N * C + tc) * 16 + i * 4;
-	double s = 0.0;
-	if (m & 1) s += M[0];
-	if (m & 2) s += M[1];
-	if (m & 4) s += M[2];
-	if (m & 8) s += M[3];
-	dptab[idx] = s;
-}
-
-// ------------------------------------------------------------------------------------------------
-// 4-state kernels.  Workgroup = (64 lanes = patterns) x (C waves = categories) x (G pattern groups);
-// a wave's category is uniform, so its 4x4 matrices live in SGPRs and feed v_fma_f64 directly.
-// Cross-category quantities (rescaling max, mixture sums) go through a small LDS exchange.
-//
-// Fringe fusion: an internal node whose subtree is a cherry (tip, tip) or a cherry plus a tip is never written to
-// HBM.  Wherever its partial is needed it is recomputed from 2-3 tip bytes in registers, and in the pre-order pass
-// its upper partial is pushed down through it in registers, yielding the gradients of its 2-4 inner branches in the
-// same kernel.  Half of the internal nodes of a random tree are of these two shapes, so both passes move about half
-// the bytes.  (The unfused schedule of keep_partials runs the same kernels with only tip / stored children.)
-// ------------------------------------------------------------------------------------------------
-// lower: stored partials, array `core` at lower + core * C*P*4, layout [C][P][4] (the reference's)
-// tipmask: [T][P] 4-bit ambiguity masks
-// lscale: [cores][P] cumulative log scale factors (SCALE only)
-
-struct Ctx4 {
-	const uint8_t *__restrict__ tipmask;
-	const double *__restrict__ mats;
-	const double *__restrict__ tiptab;
-	int P, C, c, k;
-	// P_t . tip vector: one gather from the per-(tip, category) table of the 16 possible masks
-	__device__ __forceinline__ d4 tipmsg(int t) const {
-		const unsigned m = tipmask[(size_t)t * P + k];
-		return load4(tiptab + (((size_t)t * C + c) * 16 + m) * 4);
-	}
-	__device__ __forceinline__ cptr M(int node) const { return opaque(as_const(mats + ((size_t)node * C + c) * 16)); }
-};
-
-// message of one child to its parent, P_child . p_child, at (pattern k, category c): a tip (table gather), a stored
-// array, or a fringe subtree recomputed in registers
-__device__ __forceinline__ d4 child_message(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
-                                            const double *__restrict__ lower, size_t plane) {
-	if (kind == CH_TIP) return x.tipmsg(node);
-	if (kind == CH_CORE) return matvec4(x.M(node), load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4));
-	const d4 cherry = mul4(x.tipmsg(t0), x.tipmsg(t1));
-	if (kind == CH_CHERRY) return matvec4(x.M(node), cherry);
-	return matvec4(x.M(node), mul4(matvec4(x.M(inner), cherry), x.tipmsg(t2)));  // CH_CHERRY_TIP
-}
-// same, also handing back p_child itself, which the substitution-parameter gradient contracts with dP/dtheta
-__device__ __forceinline__ d4 child_message_pre(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
-                                                const double *__restrict__ lower, size_t plane, d4 &pre) {
-	if (kind == CH_TIP) return x.tipmsg(node);
-	if (kind == CH_CORE) pre = load4(lower + ((size_t)core * x.C + x.c) * plane + (size_t)x.k * 4);
-	else {
-		pre = mul4(x.tipmsg(t0), x.tipmsg(t1));                                            // cherry
-		if (kind == CH_CHERRY_TIP) pre = mul4(matvec4(x.M(inner), pre), x.tipmsg(t2));    // cherry + tip
-	}
-	return matvec4(x.M(node), pre);
-}
-
-// dynamic LDS: 4 * G*C*64 doubles (two double-buffered exchanges) + G doubles (reduction)
-template <int WAVES, bool SCALE, bool ROOT>
-__global__ __launch_bounds__(WAVES *WAVE) void k_lower4(const NodeOp *__restrict__ ops, int T, int P, int C,
-                                                        const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
-                                                        const double *__restrict__ mats, const double *__restrict__ tiptab,
-                                                        double *__restrict__ lscale,
-                                                        const double *__restrict__ freqs, const double *__restrict__ props,
-                                                        const double *__restrict__ weights, double *__restrict__ pattern_lk,
-                                                        double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
-	extern __shared__ double sh[];
-	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
-	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
-	const NodeOp op = ops[blockIdx.y];
-	const size_t plane = (size_t)P * 4;  // one category of one node
-	double *dst = lower + ((size_t)op.core_parent * C + c) * plane;
-	const int xsz = G * C * WAVE;  // one exchange buffer
-	double acc = 0.0;
-
-#pragma unroll 1
-	for (int q = 0; q < PPT_LOWER; q++) {
-		const int k0 = ((blockIdx.x * PPT_LOWER + q) * G + g) * WAVE + lane;
-		const bool valid = k0 < P;
-		const Ctx4 x{tipmask, mats, tiptab, P, C, c, valid ? k0 : P - 1};
-		const int k = x.k;
-		const d4 a = child_message(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
-		const d4 b = child_message(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
-		d4 out = mul4(a, b);
-		double sf = 0.0;
-		if (SCALE) {  // SingleTreeLikelihood_scalePartials (treelikelihood.c:1790-1836): max over categories and states
-			double *xb = sh + (q & 1) * xsz;
-			xb[(g * C + c) * WAVE + lane] = max4(out);
-			__syncthreads();
-			double m = 0.0;
-			for (int cc = 0; cc < C; cc++) m = fmax(m, xb[(g * C + cc) * WAVE + lane]);
-			if (m < SCALING_THRESHOLD) {
-				out = d4{out.x / m, out.y / m, out.z / m, out.w / m};
-				sf = log(m);
-			}
-			if (op.kind_left == CH_CORE) sf += lscale[(size_t)op.core_left * P + k];
-			if (op.kind_right == CH_CORE) sf += lscale[(size_t)op.core_right * P + k];
-			if (c == 0 && valid) lscale[(size_t)op.core_parent * P + k] = sf;
-		}
-		if (valid) store4(dst + (size_t)k * 4, out);
-		if (ROOT) {  // integrate_partials + node_log_likelihoods + weighted sum (treelikelihood.c:1473-1487)
-			double *yb = sh + (2 + (q & 1)) * xsz;
-			yb[(g * C + c) * WAVE + lane] = props[c] * (freqs[0] * out.x + freqs[1] * out.y + freqs[2] * out.z + freqs[3] * out.w);
-			__syncthreads();
-			if (c == 0) {
-				double L = 0.0;
-				for (int cc = 0; cc < C; cc++) L += yb[(g * C + cc) * WAVE + lane];
-				const double lk = log(L) + sf;
-				if (valid) {
-					const double w = weights[k];
-					pattern_lk[k] = lk;
-					if (!SCALE) w_over_L[k] = w / L;  // the gradient's w_k / L_k (treelikelihood.c:2879), formed once per pattern
-					acc += lk * w;
-				}
-			}
-		}
-	}
-	if (ROOT) {
-		double *red = sh + 4 * xsz;
-		const double s = wave_sum(acc);
-		if (lane == 0 && c == 0) red[g] = s;
-		__syncthreads();
-		if (lane == 0 && c == 0 && g == 0) {
-			double t = red[0];
-			for (int gg = 1; gg < G; gg++) t += red[gg];
-			lnl_part[blockIdx.x] = t;
-		}
-	}
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Tree-walk form of the post-order pass (unscaled evaluations).  Patterns are independent, so instead of one launch
-// per tree level a workgroup keeps its 64*G*PPT_WALK patterns (PPT_WALK = 1 or 2, by shard size) and walks ALL core nodes itself, in depth-first
-// post-order (larger subtree first).  The op before a node is then always one of its children: that child's partial
-// is taken from registers instead of being read back (it is still stored once for the pre-order pass), and the other
-// child was written by this very thread a short subtree ago, often still in L2 / Infinity Cache.  One launch, no
-// level barriers; the root's integration happens after the loop on the carried root partial.
-// dynamic LDS: G*C*64 doubles (root exchange) + G doubles
-// ------------------------------------------------------------------------------------------------
-template <int WAVES, int PPT_WALK, bool SCALE>
-__global__ __launch_bounds__(WAVES *WAVE) void k_lower4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
-                                                             const uint8_t *__restrict__ tipmask, double *__restrict__ lower,
-                                                             const double *__restrict__ mats, const double *__restrict__ tiptab,
-                                                             double *__restrict__ lscale,
-                                                             const double *__restrict__ freqs, const double *__restrict__ props,
-                                                             const double *__restrict__ weights, double *__restrict__ pattern_lk,
-                                                             double *__restrict__ w_over_L, double *__restrict__ lnl_part) {
-	// dynamic LDS: root exchange G*C*64 + G doubles; SCALE: + two G*C*64 buffers for the per-op maximum over categories
-	extern __shared__ double sh[];
-	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
-	const size_t plane = (size_t)P * 4;
-	const int xsz = G * C * WAVE;
-	int kq[PPT_WALK];
-	bool vq[PPT_WALK];
-#pragma unroll
-	for (int q = 0; q < PPT_WALK; q++) {
-		const int k0 = ((blockIdx.x * PPT_WALK + q) * G + g) * WAVE + lane;
-		vq[q] = k0 < P;
-		kq[q] = vq[q] ? k0 : P - 1;
-	}
-	d4 carry[PPT_WALK];
-	double sfc[PPT_WALK];  // SCALE: cumulative log scale factor of the carried partial
-#pragma unroll
-	for (int q = 0; q < PPT_WALK; q++) {
-		carry[q] = d4{0., 0., 0., 0.};
-		sfc[q] = 0.0;
-	}
-	int flip = 0;
-#pragma unroll 1
-	for (int i = 0; i < nops; i++) {
-		const NodeOp *op = ops + i;  // wave-uniform: scalar loads
-		const int cin = op->carry_in;
-		double *dst = lower + ((size_t)op->core_parent * C + c) * plane;
-#pragma unroll
-		for (int q = 0; q < PPT_WALK; q++) {
-			const Ctx4 x{tipmask, mats, tiptab, P, C, c, kq[q]};
-			const d4 a = cin == 1 ? matvec4(x.M(op->left), carry[q])
-			                      : child_message(x, op->kind_left, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, lower, plane);
-			const d4 b = cin == 2 ? matvec4(x.M(op->right), carry[q])
-			                      : child_message(x, op->kind_right, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, lower, plane);
-			d4 out = mul4(a, b);
-			if (SCALE) {  // SingleTreeLikelihood_scalePartials (treelikelihood.c:1790-1836): max over categories and states
-				double *xb = sh + xsz + G + (flip & 1) * xsz;
-				flip++;
-				xb[(g * C + c) * WAVE + lane] = max4(out);
-				__syncthreads();
-				double m = 0.0, sf = 0.0;
-				for (int cc = 0; cc < C; cc++) m = fmax(m, xb[(g * C + cc) * WAVE + lane]);
-				if (m < SCALING_THRESHOLD) {
-					out = d4{out.x / m, out.y / m, out.z / m, out.w / m};
-					sf = log(m);
-				}
-				if (op->kind_left == CH_CORE) sf += cin == 1 ? sfc[q] : lscale[(size_t)op->core_left * P + kq[q]];
-				if (op->kind_right == CH_CORE) sf += cin == 2 ? sfc[q] : lscale[(size_t)op->core_right * P + kq[q]];
-				if (c == 0 && vq[q]) lscale[(size_t)op->core_parent * P + kq[q]] = sf;
-				sfc[q] = sf;
-			}
-			if (vq[q]) store4(dst + (size_t)kq[q] * 4, out);
-			carry[q] = out;
-		}
-	}
-	// the last op is the root: integrate_partials + node_log_likelihoods + weighted sum (treelikelihood.c:1473-1487)
-	double acc = 0.0;
-#pragma unroll
-	for (int q = 0; q < PPT_WALK; q++) {
-		const d4 out = carry[q];
-		__syncthreads();
-		sh[(g * C + c) * WAVE + lane] = props[c] * (freqs[0] * out.x + freqs[1] * out.y + freqs[2] * out.z + freqs[3] * out.w);
-		__syncthreads();
-		if (c == 0) {
-			double L = 0.0;
-			for (int cc = 0; cc < C; cc++) L += sh[(g * C + cc) * WAVE + lane];
-			const double lk = log(L) + (SCALE ? sfc[q] : 0.0);
-			if (vq[q]) {
-				const double w = weights[kq[q]];
-				pattern_lk[kq[q]] = lk;
-				if (!SCALE) w_over_L[kq[q]] = w / L;
-				acc += lk * w;
-			}
-		}
-	}
-	double *red = sh + xsz;
-	const double s = wave_sum(acc);
-	if (lane == 0 && c == 0) red[g] = s;
-	__syncthreads();
-	if (lane == 0 && c == 0 && g == 0) {
-		double t = red[0];
-		for (int gg = 1; gg < G; gg++) t += red[gg];
-		lnl_part[blockIdx.x] = t;
-	}
-}
-
-// ------------------------------------------------------------------------------------------------
-// K7 + K8 fused, 4 states: one level of the pre-order pass
-// ------------------------------------------------------------------------------------------------
-// For a parent p with children l, r, per (pattern k, category c):
-//   a   = P_p u_p                      (parent is the root: a = pi if FOLD else 1)
-//   bl  = P_l p_l,  br = P_r p_r
-//   u_l = a o br,   u_r = a o bl                                       (treelikelihood.c:2142-2147)
-//   den_c  = sum_i f_i a_i bl_i br_i      = L_kc in this branch's (scaled) units
-//   num_lc = sum_i f_i u_l,i (Q bl)_i     since (dP/dt) p = Q P p     (treelikelihood.c:2846-2939), f = 1 if FOLD else pi
-//   g[l][c] += w_k num_lc / L_k.  Unscaled: w_k / L_k comes from the root kernel.  Rescaled: L_k in this branch's
-//   units = sum_c' w_c' den_c' (COMPAT: den_c alone, treelikelihood.c:2851-2870)
-// A fringe child continues in registers: its upper is pushed through its cherry (and inner cherry), producing the
-// gradients of the 2-4 branches inside it (accumulators e[0..3]).
-// upper: slot s at upper + s * C*P*4.  gpart: [(N*C)][nblk] per-block partial sums.
-// dynamic LDS: SCALE: 6 * G*C*64 doubles (three double-buffered exchanges); then NACC * waves * 64 doubles (reduction)
-
-constexpr int NACC = 10;  // gradient accumulators per thread: 2 children + 4 + 4 fringe branches
-constexpr int WCOL = WAVE + 2;  // tree-walk kernel: LDS column stride (padding spreads the quarter-column readers over the banks)
-
-struct Grad4 {
-	cptr Q;
-	d4 f;
-	double wl;
-	double *acc;  // this thread's accumulators in LDS: acc[i * WAVE] (lane-interleaved, conflict-free)
-	// substitution-parameter side (PARAMS kernels only): dP/dtheta per (parameter, node, category) and their tip tables
-	const double *__restrict__ dpm;    // [NP][N][C][16]
-	const double *__restrict__ dptab;  // [NP][T][C][16][4]
-	int np, N, T;
-	double wc;                         // category proportion: parameter terms are summed over categories
-	// acc[i] += w_k / L_k * sum_i f_i u_i (Q b)_i
-	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const {
-		acc[i * WAVE] += wl * dot4(mul4(f, u), matvec4(opaque(Q), b));
-	}
-	// acc[NACC + th] += w_c w_k / L_k sum_i f_i u_i (dP_th,node p)_i   (calculate_dlnl_dQ, treelikelihood.c:2472-2580)
-	__device__ __forceinline__ void addp_vec(const Ctx4 &x, int node, const d4 &u, const d4 &p) const {
-		const d4 fu = mul4(f, u);
-		for (int th = 0; th < np; th++) {
-			const cptr D = opaque(as_const(dpm + (((size_t)th * N + node) * x.C + x.c) * 16));
-			acc[(NACC + th) * WAVE] += wc * wl * dot4(fu, matvec4(D, p));
-		}
-	}
-	__device__ __forceinline__ void addp_tip(const Ctx4 &x, int tip, const d4 &u) const {
-		const d4 fu = mul4(f, u);
-		const unsigned m = x.tipmask[(size_t)tip * x.P + x.k];
-		for (int th = 0; th < np; th++)
-			acc[(NACC + th) * WAVE] += wc * wl * dot4(fu, load4(dptab + ((((size_t)th * T + tip) * x.C + x.c) * 16 + m) * 4));
-	}
-};
-
-// push upper `u` of a fringe child (node `node`) down to its inner branches; accumulators base..base+3:
-//   CH_CHERRY     : +0 -> t0, +1 -> t1
-//   CH_CHERRY_TIP : +0 -> t0, +1 -> t1 (inside the inner cherry), +2 -> inner, +3 -> t2
-// Ordered so that few vectors are live at once (the kernel is register-limited).
-// tree-walk kernel: one pattern per thread, so every branch term is written exactly once per op (no read-modify-write);
-// Q is diag(pi) Q (or Q when the frequencies are folded into the uppers), so there is no separate state weight.
-// PARAMS: every gradient site also feeds the substitution-parameter gradient, accumulated in the eigen basis:
-//   d lnL / d theta = sum_ab B_theta,ab G_ab,   G_ab = sum_sites w_c F_ab(t r_c) (w_k / L_k) a_a b_b,
-//   a = U^T (pi o u),  b = U^-1 p,  B_theta = U^-1 dQ_theta U,  F as in dPdp_with_dQdp (substmodel.c:469-489)
-// -- 16 accumulators per thread whatever the number of parameters, two extra mat-vecs and 16 multiply-adds per site
-// (the reference walks the tree once per parameter; the level kernels contract with one dP/dtheta per parameter).
-struct ParamCtx {
-	cptr UTpi, Uinv;     // (diag(pi) U)^T and U^-1, 4x4 row-major
-	const double *utab;  // [16][4]: U^-1 . tip mask
-	const double *Fw;    // [N][C][16]: w_c F_ab(t_n r_c)
-};
-// SCALE (rescaled evaluations): the branch term is w_k (num / D_k) with D_k the site likelihood in the op's scaled units --
-// quotient first, num and D can both be denormal -- and the parameter sums weight with wl = w_k / D_k.
-template <bool PARAMS, bool SCALE>
-struct GradWT {
-	cptr Q;
-	double wl;
-	double *col;  // this thread's NACC slots in LDS, stride WCOL
-	ParamCtx pc;
-	double *G;    // [16], registers of the kernel
-	double w, d;  // SCALE only
-	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const {
-		const double num = dot4(u, matvec4(opaque(Q), b));
-		col[i * WCOL] = SCALE ? w * (num / d) : wl * num;
-	}
-	__device__ __forceinline__ void accumulate(const Ctx4 &x, int node, const d4 &a, const d4 &b) const {
-		const cptr F = opaque(as_const(pc.Fw + ((size_t)node * x.C + x.c) * 16));
-		const double t0 = wl * a.x, t1 = wl * a.y, t2 = wl * a.z, t3 = wl * a.w;
-		G[0] += (F[0] * t0) * b.x;
-		G[1] += (F[1] * t0) * b.y;
-		G[2] += (F[2] * t0) * b.z;
-		G[3] += (F[3] * t0) * b.w;
-		G[4] += (F[4] * t1) * b.x;
-		G[5] += (F[5] * t1) * b.y;
-		G[6] += (F[6] * t1) * b.z;
-		G[7] += (F[7] * t1) * b.w;
-		G[8] += (F[8] * t2) * b.x;
-		G[9] += (F[9] * t2) * b.y;
-		G[10] += (F[10] * t2) * b.z;
-		G[11] += (F[11] * t2) * b.w;
-		G[12] += (F[12] * t3) * b.x;
-		G[13] += (F[13] * t3) * b.y;
-		G[14] += (F[14] * t3) * b.z;
-		G[15] += (F[15] * t3) * b.w;
-		__builtin_amdgcn_sched_barrier(0);
-	}
-	// a branch with a computed lower partial p (stored node, cherry product, ...) / a tip branch with mask m
-	__device__ __forceinline__ void site_vec(const Ctx4 &x, int node, const d4 &u, const d4 &p) const {
-		if (PARAMS) accumulate(x, node, matvec4(opaque(pc.UTpi), u), matvec4(opaque(pc.Uinv), p));
-	}
-	__device__ __forceinline__ void site_tip(const Ctx4 &x, int tip, const d4 &u, unsigned m) const {
-		if (PARAMS) accumulate(x, tip, matvec4(opaque(pc.UTpi), u), load4(pc.utab + m * 4));
-	}
-};
-
-// rescaled evaluations: the branch term is w_k num / D_k with D_k the site likelihood in the op's scaled units; the quotient
-// is formed first (num and D can both be denormal when a category has underflowed)
-struct GradS {
-	cptr Q;
-	d4 f;
-	double w, d;
-	double *acc;
-	__device__ __forceinline__ void add(int i, const d4 &u, const d4 &b) const { acc[i * WAVE] += w * (dot4(mul4(f, u), matvec4(opaque(Q), b)) / d); }
-	__device__ __forceinline__ void addp_vec(const Ctx4 &, int, const d4 &, const d4 &) const {}
-	__device__ __forceinline__ void addp_tip(const Ctx4 &, int, const d4 &) const {}
-};
-// only the substitution-parameter terms of a Grad4 (used next to GradS)
-struct GradPOnly {
-	const Grad4 &g;
-	__device__ __forceinline__ void add(int, const d4 &, const d4 &) const {}
-	__device__ __forceinline__ void addp_vec(const Ctx4 &x, int node, const d4 &u, const d4 &p) const { g.addp_vec(x, node, u, p); }
-	__device__ __forceinline__ void addp_tip(const Ctx4 &x, int tip, const d4 &u) const { g.addp_tip(x, tip, u); }
-};
-
-template <bool PARAMS, typename GradT>
-__device__ __forceinline__ void descend_fringe(const Ctx4 &x, const GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
-                                               const d4 &u) {
-	const d4 b0 = x.tipmsg(t0), b1 = x.tipmsg(t1);
-	d4 a2 = matvec4(x.M(node), u);
-	if (kind == CH_CHERRY_TIP) {
-		const d4 pn = mul4(b0, b1);
-		const d4 bn = matvec4(x.M(inner), pn);
-		const d4 b2 = x.tipmsg(t2);
-		const d4 un = mul4(a2, b2);
-		gr.add(base + 2, un, bn);
-		gr.add(base + 3, mul4(a2, bn), b2);
-		if (PARAMS) {
-			gr.addp_vec(x, inner, un, pn);
-			gr.addp_tip(x, t2, mul4(a2, bn));
-		}
-		a2 = matvec4(x.M(inner), un);  // now the upper message entering the inner cherry
-	}
-	gr.add(base + 0, mul4(a2, b1), b0);
-	gr.add(base + 1, mul4(a2, b0), b1);
-	if (PARAMS) {
-		gr.addp_tip(x, t0, mul4(a2, b1));
-		gr.addp_tip(x, t1, mul4(a2, b0));
-	}
-}
-
-template <int WAVES, bool SCALE, bool FOLD, bool COMPAT, bool PARAMS>
-__global__ __launch_bounds__(WAVES *WAVE, (WAVES == 4 && !PARAMS) ? PHYAMD_UPPER_MIN_WAVES : 1) void k_upper4(const NodeOp *__restrict__ ops, int T, int P, int C,
-                                                        const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
-                                                        double *__restrict__ upper, const double *__restrict__ mats,
-                                                        const double *__restrict__ tiptab, const double *__restrict__ Q,
-                                                        const double *__restrict__ freqs,
-                                                        const double *__restrict__ props, const double *__restrict__ weights,
-                                                        const double *__restrict__ w_over_L, double *__restrict__ gpart, int nblk,
-                                                        const double *__restrict__ dpm, const double *__restrict__ dptab, int np, int N,
-                                                        double *__restrict__ ppart, int op_base, int op_total) {
-	extern __shared__ double sh[];
-	// blockDim.x == 64: threadIdx.y/z are wave-uniform; readfirstlane tells the compiler so (SGPR addressing)
-	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
-	const NodeOp op = ops[blockIdx.y];
-	const size_t plane = (size_t)P * 4;
-	const bool proot = op.upper_slot_parent < 0;
-	const int nacc = NACC + (PARAMS ? np : 0);  // accumulator columns per thread
-	const double *up = proot ? nullptr : upper + ((size_t)op.upper_slot_parent * C + c) * plane;
-	double *ul_dst = op.upper_slot_left < 0 ? nullptr : upper + ((size_t)op.upper_slot_left * C + c) * plane;
-	double *ur_dst = op.upper_slot_right < 0 ? nullptr : upper + ((size_t)op.upper_slot_right * C + c) * plane;
-	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
-	const d4 one = d4{1., 1., 1., 1.};
-	const int xsz = G * C * WAVE;
-	// gradient accumulators live in LDS (one column per thread), not in registers: the kernel is VGPR-limited
-	const int wv = g * C + c, nw = G * C;
-	double *red = sh + (SCALE ? 6 * xsz : 0);
-	Grad4 gr{as_const(Q), FOLD ? one : pi, 0.0, red + (size_t)wv * nacc * WAVE + lane, dpm, dptab, np, N, T, props[c]};
-	for (int i = 0; i < nacc; i++) gr.acc[i * WAVE] = 0.0;
-
-#pragma unroll 1
-	for (int q = 0; q < PPT_UPPER; q++) {
-		const int k0 = ((blockIdx.x * PPT_UPPER + q) * G + g) * WAVE + lane;
-		const bool valid = k0 < P;
-		const Ctx4 x{tipmask, mats, tiptab, P, C, c, valid ? k0 : P - 1};
-		const int k = x.k;
-		d4 prel = one, prer = one;  // the children's own partials (PARAMS only)
-		const d4 bl = PARAMS ? child_message_pre(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane, prel)
-		                     : child_message(x, op.kind_left, op.left, op.core_left, op.lt0, op.lt1, op.lt2, op.linner, lower, plane);
-		const d4 br = PARAMS ? child_message_pre(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane, prer)
-		                     : child_message(x, op.kind_right, op.right, op.core_right, op.rt0, op.rt1, op.rt2, op.rinner, lower, plane);
-		const d4 a = proot ? (FOLD ? pi : one) : matvec4(x.M(op.parent), load4(up + (size_t)k * 4));
-		d4 ul = mul4(a, br), ur = mul4(a, bl);
-		if (!SCALE) {
-			// unscaled: divide by the site likelihood formed at the root, like the reference (treelikelihood.c:2879);
-			// no cross-category exchange, no barrier, no division in this kernel
-			gr.wl = valid ? w_over_L[k] : 0.0;
-			gr.add(0, ul, bl);
-			gr.add(1, ur, br);
-			if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
-			if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
-			if (PARAMS) {
-				if (op.kind_left == CH_TIP) gr.addp_tip(x, op.left, ul);
-				else gr.addp_vec(x, op.left, ul, prel);
-				if (op.kind_right == CH_TIP) gr.addp_tip(x, op.right, ur);
-				else gr.addp_vec(x, op.right, ur, prer);
-			}
-			if (op.kind_left >= CH_CHERRY) descend_fringe<PARAMS>(x, gr, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
-			if (op.kind_right >= CH_CHERRY) descend_fringe<PARAMS>(x, gr, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
-			continue;
-		} else {
-			// rescaled: L_k underflows by construction, so the mixture likelihood is re-formed
-			// in this branch's scaled units from all categories' den (exchange through LDS); the scale factors cancel in num / D
-			const double den = dot4(mul4(gr.f, a), mul4(bl, br));
-			const double numl = dot4(mul4(gr.f, ul), matvec4(opaque(gr.Q), bl));
-			const double numr = dot4(mul4(gr.f, ur), matvec4(opaque(gr.Q), br));
-			double *xb = sh + (q & 1) * 3 * xsz;
-			const int xi = (g * C + c) * WAVE + lane;
-			xb[xi] = props[c] * den;
-			xb[xsz + xi] = max4(ul);
-			xb[2 * xsz + xi] = max4(ur);
-			__syncthreads();
-			double D = 0.0, ml = 0.0, mr = 0.0;
-			for (int cc = 0; cc < C; cc++) {
-				D += xb[(g * C + cc) * WAVE + lane];
-				ml = fmax(ml, xb[xsz + (g * C + cc) * WAVE + lane]);
-				mr = fmax(mr, xb[2 * xsz + (g * C + cc) * WAVE + lane]);
-			}
-			// num / L first: with COMPAT both can be denormal (a category that has underflowed) and 1 / den alone overflows
-			const double w = valid ? weights[k] : 0.0, d = COMPAT ? den : D;
-			gr.acc[0] += w * (numl / d);
-			gr.acc[WAVE] += w * (numr / d);
-			if (PARAMS) {  // mixture numerator over the mixture likelihood in this branch's units (treelikelihood.c:2545-2556)
-				gr.wl = w / D;
-				if (op.kind_left == CH_TIP) gr.addp_tip(x, op.left, ul);
-				else gr.addp_vec(x, op.left, ul, prel);
-				if (op.kind_right == CH_TIP) gr.addp_tip(x, op.right, ur);
-				else gr.addp_vec(x, op.right, ur, prer);
-			}
-			// Fringe children (fused schedules run rescaled too): a cherry or cherry + tip never reaches the rescaling threshold
-			// (products of two or three transition probabilities), so its likelihood is in this op's units and shares D
-			if (op.kind_left >= CH_CHERRY || op.kind_right >= CH_CHERRY) {
-				const GradS gs{gr.Q, gr.f, w, d, gr.acc};
-				if (op.kind_left >= CH_CHERRY) descend_fringe<false>(x, gs, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
-				if (op.kind_right >= CH_CHERRY) descend_fringe<false>(x, gs, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
-				if (PARAMS) {
-					const GradPOnly gp{gr};  // gr.wl = w / D from above
-					if (op.kind_left >= CH_CHERRY) descend_fringe<true>(x, gp, 2, op.kind_left, op.left, op.lt0, op.lt1, op.lt2, op.linner, ul);
-					if (op.kind_right >= CH_CHERRY) descend_fringe<true>(x, gp, 6, op.kind_right, op.right, op.rt0, op.rt1, op.rt2, op.rinner, ur);
-				}
-			}
-			// uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
-			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
-			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
-		}
-		if (ul_dst && valid) store4(ul_dst + (size_t)k * 4, ul);
-		if (ur_dst && valid) store4(ur_dst + (size_t)k * 4, ur);
-	}
-	// Fixed-order reduction over the workgroup's patterns: the accumulators sit in LDS as [wave][acc][lane];
-	// one lane per (wave, accumulator) adds the 64 entries in lane order; wave 0 of each category adds the pattern groups.
-	__syncthreads();
-	if (lane < nacc) {
-		const double *src = red + ((size_t)wv * nacc + lane) * WAVE;
-		double s0 = src[0], s1 = src[16], s2 = src[32], s3 = src[48];  // four chains of 16, then a fixed combine
-		for (int j = 1; j < 16; j++) {
-			s0 += src[j];
-			s1 += src[16 + j];
-			s2 += src[32 + j];
-			s3 += src[48 + j];
-		}
-		const double s = (s0 + s1) + (s2 + s3);
-		red[(size_t)nw * nacc * WAVE + wv * nacc + lane] = s;
-	}
-	__syncthreads();
-	const double *tot = red + (size_t)nw * nacc * WAVE;
-	if (g == 0 && lane < NACC) {
-		double s = tot[c * nacc + lane];
-		for (int gg = 1; gg < G; gg++) s += tot[(gg * C + c) * nacc + lane];
-		// accumulator -> gradient row (node id); -1 = unused for this op
-		const int kl = op.kind_left, kr = op.kind_right;
-		int node = -1;
-		switch (lane) {
-			case 0: node = op.left; break;
-			case 1: node = op.right; break;
-			case 2: node = kl >= CH_CHERRY ? op.lt0 : -1; break;
-			case 3: node = kl >= CH_CHERRY ? op.lt1 : -1; break;
-			case 4: node = kl == CH_CHERRY_TIP ? op.linner : -1; break;
-			case 5: node = kl == CH_CHERRY_TIP ? op.lt2 : -1; break;
-			case 6: node = kr >= CH_CHERRY ? op.rt0 : -1; break;
-			case 7: node = kr >= CH_CHERRY ? op.rt1 : -1; break;
-			case 8: node = kr == CH_CHERRY_TIP ? op.rinner : -1; break;
-			case 9: node = kr == CH_CHERRY_TIP ? op.rt2 : -1; break;
-		}
-		if (node >= 0) gpart[((size_t)node * C + c) * nblk + blockIdx.x] = s;
-	}
-	if (PARAMS && wv == 0 && lane < np) {  // parameter terms: sum over all waves (categories and pattern groups) in a fixed order
-		double s = 0.0;
-		for (int w = 0; w < nw; w++) s += tot[w * nacc + NACC + lane];
-		ppart[((size_t)lane * op_total + op_base + blockIdx.y) * nblk + blockIdx.x] = s;
-	}
-}
-
-// Variants for the pre-order tree walk: the mask bytes of an op's (up to six) tips are all requested at the top of the op,
-// together with the parent's upper, so the op pays one memory round trip for them instead of one per child.
-__device__ __forceinline__ d4 tip_gather(const Ctx4 &x, int t, unsigned m) { return load4(x.tiptab + (((size_t)t * x.C + x.c) * 16 + m) * 4); }
-// `pre` receives the child's own partial (what the parameter gradient contracts): untouched for tips
-__device__ __forceinline__ d4 child_message_m(const Ctx4 &x, int kind, int node, int core, int t0, int t1, int t2, int inner,
-                                              const d4 &pcore, unsigned m0, unsigned m1, unsigned m2, d4 &pre) {
-	if (kind == CH_TIP) return tip_gather(x, node, m0);
-	if (kind == CH_CORE) pre = pcore;
-	else {
-		pre = mul4(tip_gather(x, t0, m0), tip_gather(x, t1, m1));                                    // cherry
-		if (kind == CH_CHERRY_TIP) pre = mul4(matvec4(x.M(inner), pre), tip_gather(x, t2, m2));   // cherry + tip
-	}
-	return matvec4(x.M(node), pre);
-}
-template <typename GradT>
-__device__ __forceinline__ void descend_fringe_m(const Ctx4 &x, const GradT &gr, int base, int kind, int node, int t0, int t1, int t2, int inner,
-                                                 const d4 &u, unsigned m0, unsigned m1, unsigned m2) {
-	const d4 b0 = tip_gather(x, t0, m0), b1 = tip_gather(x, t1, m1);
-	d4 a2 = matvec4(x.M(node), u);
-	if (kind == CH_CHERRY_TIP) {
-		const d4 pn = mul4(b0, b1);
-		const d4 bn = matvec4(x.M(inner), pn);
-		const d4 b2 = tip_gather(x, t2, m2);
-		const d4 un = mul4(a2, b2);
-		gr.add(base + 2, un, bn);
-		gr.add(base + 3, mul4(a2, bn), b2);
-		gr.site_vec(x, inner, un, pn);
-		gr.site_tip(x, t2, mul4(a2, bn), m2);
-		a2 = matvec4(x.M(inner), un);  // now the upper message entering the inner cherry
-	}
-	gr.add(base + 0, mul4(a2, b1), b0);
-	gr.add(base + 1, mul4(a2, b0), b1);
-	gr.site_tip(x, t0, mul4(a2, b1), m0);
-	gr.site_tip(x, t1, mul4(a2, b0), m1);
-}
-
-// sum 16 per-lane values over the 64 lanes of a wave in 17 exchange steps (instead of 16 x 6): after the xor-32 step a
-// lane keeps only half of the values, after xor-16 a quarter, ...  Returns, in every lane, the wave total of value
-// index ((lane >> 2) & 15) with bits taken as (bit5, bit4, bit3, bit2) -> (8, 4, 2, 1).  Fixed order: deterministic.
-__device__ __forceinline__ double wave_sum16(const double (&v)[16], int lane) {
-	double a8[8], a4[4], a2[2];
-	const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
-#pragma unroll
-	for (int i = 0; i < 8; i++) a8[i] = (h5 ? v[i + 8] : v[i]) + __shfl_xor(h5 ? v[i] : v[i + 8], 32, 64);
-#pragma unroll
-	for (int i = 0; i < 4; i++) a4[i] = (h4 ? a8[i + 4] : a8[i]) + __shfl_xor(h4 ? a8[i] : a8[i + 4], 16, 64);
-#pragma unroll
-	for (int i = 0; i < 2; i++) a2[i] = (h3 ? a4[i + 2] : a4[i]) + __shfl_xor(h3 ? a4[i] : a4[i + 2], 8, 64);
-	double a1 = (h2 ? a2[1] : a2[0]) + __shfl_xor(h2 ? a2[0] : a2[1], 4, 64);
-	a1 += __shfl_xor(a1, 2, 64);
-	a1 += __shfl_xor(a1, 1, 64);
-	return a1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tree-walk form of the pre-order pass + branch gradient (unscaled evaluations), the counterpart of k_lower4_walk: a
-// workgroup keeps its patterns (ONE per thread) and visits every core node in depth-first pre-order, smaller core subtree
-// first.  The upper partial of the child visited next never leaves registers (no store, no load); the other core child's
-// upper is parked in one of ~log2(core nodes) recycled slots and read back by the same thread after the small subtree.
-// The branch terms of an op go to LDS columns (written once per op) and are reduced over the wave by wave_sum16, then
-// written to the gradient slab: gpart[(node * C + c) * nblk + blockIdx.x * G + g], nblk = gridDim.x * G.
-// Register-lean on purpose (<= 96 VGPRs, 5 waves per SIMD): the walk is bound by dependent latency chains (tip byte ->
-// table gather -> mat-vec, scalar matrix loads), so resident waves matter more than per-op amortisation; a form with 4
-// patterns per thread, carried uppers in LDS and accumulators in registers (126 VGPRs, 4 waves) measured 14 % slower.
-// dynamic LDS: [waves][NACC][WCOL] doubles
-// ------------------------------------------------------------------------------------------------
-#ifndef PHYAMD_WALK_UPPER_MIN_WAVES
-#define PHYAMD_WALK_UPPER_MIN_WAVES 5
-#endif
-// PARAMS: dynamic LDS holds 16 columns per wave (the eigen-basis sums are reduced once, after the walk); pbuf = [UTpi(16) |
-// Uinv(16) | utab(64)], Fw as in ParamCtx, gacc [16][nblk] receives the per-wave sums.
-// SCALE / COMPAT: rescaled evaluations (see k_upper4): one LDS exchange per op gives every category's wave the mixture
-// denominator D_k and the maxima of the two new uppers; dynamic LDS grows by 6 * waves * 64 doubles (double-buffered).
-template <int WAVES, bool FOLD, bool PARAMS, bool SCALE, bool COMPAT>
-__global__ __launch_bounds__(WAVES *WAVE, WAVES == 4 ? (PARAMS ? 3 : (SCALE ? 4 : PHYAMD_WALK_UPPER_MIN_WAVES)) : 1) void k_upper4_walk(const NodeOp *__restrict__ ops, int nops, int T, int P, int C,
-                                                              const uint8_t *__restrict__ tipmask, const double *__restrict__ lower,
-                                                              double *__restrict__ upper, const double *__restrict__ mats,
-                                                              const double *__restrict__ tiptab, const double *__restrict__ Q,
-                                                              const double *__restrict__ freqs, const double *__restrict__ w_over_L,
-                                                              double *__restrict__ gpart, int nblk, const double *__restrict__ pbuf,
-                                                              const double *__restrict__ Fw, double *__restrict__ gacc,
-                                                              const double *__restrict__ props, const double *__restrict__ weights) {
-	extern __shared__ double sh[];
-	constexpr int NCOL = PARAMS ? 16 : NACC;
-	const int lane = threadIdx.x, c = __builtin_amdgcn_readfirstlane(threadIdx.y), g = __builtin_amdgcn_readfirstlane(threadIdx.z), G = blockDim.z;
-	const size_t plane = (size_t)P * 4;
-	const d4 pi = d4{freqs[0], freqs[1], freqs[2], freqs[3]};
-	const d4 one = d4{1., 1., 1., 1.};
-	const int wv = g * C + c;
-	double *wave_cols = sh + (size_t)wv * NCOL * WCOL;  // this wave's columns of WCOL (= 64 + padding) doubles
-	double *col = wave_cols + lane;                     // this thread's slot in each column, stride WCOL
-	// reduction role of this lane: lanes 0..4*NACC-1 each add a quarter (16 entries) of one column
-	const int my = lane >> 2, seg = lane & 3;
-	const size_t slab = (size_t)blockIdx.x * G + g;
-	const int k0 = (blockIdx.x * G + g) * WAVE + lane;
-	const bool valid = k0 < P;
-	const int k = valid ? k0 : P - 1;
-	const Ctx4 x{tipmask, mats, tiptab, P, C, c, k};
-	const double wl = SCALE ? 0.0 : (valid ? w_over_L[k] : 0.0);
-	const double wk = SCALE ? (valid ? weights[k] : 0.0) : 0.0;
-	const int xsz = G * C * WAVE;
-	double *xbase = sh + (size_t)G * C * NCOL * WCOL;  // SCALE: exchange buffers behind the columns
-	d4 carry = one;
-	double Gab[16] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
-	const ParamCtx pc{as_const(pbuf), as_const(pbuf + 16), pbuf + 32, Fw};
-#pragma unroll 1
-	for (int i = 0; i < nops; i++) {
-		const NodeOp *op = ops + i;  // wave-uniform: scalar loads
-		const bool proot = i == 0;   // pre-order: the root comes first
-		const int cin = op->carry_in, cout = op->carry_out;
-		const int kl = op->kind_left, kr = op->kind_right;
-		GradWT<PARAMS, SCALE> gr{as_const(Q), wl, col, pc, Gab, 0.0, 1.0};  // Q is diag(pi) Q unless FOLD
-		// every tip mask byte of the op up front: all in flight together
-		unsigned ml0 = 0, ml1 = 0, ml2 = 0, mr0 = 0, mr1 = 0, mr2 = 0;
-		if (kl == CH_TIP) ml0 = tipmask[(size_t)op->left * P + k];
-		else if (kl >= CH_CHERRY) {
-			ml0 = tipmask[(size_t)op->lt0 * P + k];
-			ml1 = tipmask[(size_t)op->lt1 * P + k];
-			if (kl == CH_CHERRY_TIP) ml2 = tipmask[(size_t)op->lt2 * P + k];
-		}
-		if (kr == CH_TIP) mr0 = tipmask[(size_t)op->right * P + k];
-		else if (kr >= CH_CHERRY) {
-			mr0 = tipmask[(size_t)op->rt0 * P + k];
-			mr1 = tipmask[(size_t)op->rt1 * P + k];
-			if (kr == CH_CHERRY_TIP) mr2 = tipmask[(size_t)op->rt2 * P + k];
-		}
-		d4 uin = carry;  // the parent's upper: carried in registers, or parked by an earlier op of this thread
-		if (!proot && !cin) uin = load4(upper + ((size_t)op->upper_slot_parent * C + c) * plane + (size_t)k * 4);
-		d4 pl = one, pr = one;  // stored children
-		if (kl == CH_CORE) pl = load4(lower + ((size_t)op->core_left * C + c) * plane + (size_t)k * 4);
-		if (kr == CH_CORE) pr = load4(lower + ((size_t)op->core_right * C + c) * plane + (size_t)k * 4);
-		d4 prel = one, prer = one;  // the children's own partials (the parameter gradient contracts them)
-		const d4 bl = child_message_m(x, kl, op->left, op->core_left, op->lt0, op->lt1, op->lt2, op->linner, pl, ml0, ml1, ml2, prel);
-		const d4 br = child_message_m(x, kr, op->right, op->core_right, op->rt0, op->rt1, op->rt2, op->rinner, pr, mr0, mr1, mr2, prer);
-		d4 a;
-		if (proot) a = FOLD ? pi : one;
-		else a = matvec4(x.M(op->parent), uin);
-		d4 ul = mul4(a, br), ur = mul4(a, bl);
-		double ml = 1.0, mr = 1.0;
-		if (SCALE) {
-			// the mixture likelihood in this op's scaled units from all categories (L_k itself underflows by construction)
-			const double den = dot4(FOLD ? a : mul4(pi, a), mul4(bl, br));
-			double *xb = xbase + (size_t)(i & 1) * 3 * xsz;
-			const int xi = wv * WAVE + lane;
-			xb[xi] = props[c] * den;
-			xb[xsz + xi] = max4(ul);
-			xb[2 * xsz + xi] = max4(ur);
-			__syncthreads();
-			double D = 0.0;
-			ml = mr = 0.0;
-			for (int cc = 0; cc < C; cc++) {
-				D += xb[(g * C + cc) * WAVE + lane];
-				ml = fmax(ml, xb[xsz + (g * C + cc) * WAVE + lane]);
-				mr = fmax(mr, xb[2 * xsz + (g * C + cc) * WAVE + lane]);
-			}
-			gr.w = wk;
-			gr.d = COMPAT ? den : D;
-			gr.wl = wk / D;
-		}
-		gr.add(0, ul, bl);
-		gr.add(1, ur, br);
-		if (PARAMS) {
-			if (kl == CH_TIP) gr.site_tip(x, op->left, ul, ml0);
-			else gr.site_vec(x, op->left, ul, prel);
-			if (kr == CH_TIP) gr.site_tip(x, op->right, ur, mr0);
-			else gr.site_vec(x, op->right, ur, prer);
-		}
-		// fringe children continue in registers with the un-rescaled uppers (they share this op's units and denominator)
-		if (kl >= CH_CHERRY) descend_fringe_m(x, gr, 2, kl, op->left, op->lt0, op->lt1, op->lt2, op->linner, ul, ml0, ml1, ml2);
-		if (kr >= CH_CHERRY) descend_fringe_m(x, gr, 6, kr, op->right, op->rt0, op->rt1, op->rt2, op->rinner, ur, mr0, mr1, mr2);
-		if (SCALE) {  // uppers are rescaled like lowers (treelikelihood.c:1414, 1795-1796)
-			if (ml < SCALING_THRESHOLD) ul = d4{ul.x / ml, ul.y / ml, ul.z / ml, ul.w / ml};
-			if (mr < SCALING_THRESHOLD) ur = d4{ur.x / mr, ur.y / mr, ur.z / mr, ur.w / mr};
-		}
-		if (op->upper_slot_left >= 0 && valid) store4(upper + ((size_t)op->upper_slot_left * C + c) * plane + (size_t)k * 4, ul);
-		if (op->upper_slot_right >= 0 && valid) store4(upper + ((size_t)op->upper_slot_right * C + c) * plane + (size_t)k * 4, ur);
-		carry = cout == 1 ? ul : ur;
-		// Fixed-order sum of each column over the wave's 64 patterns: four lanes per column add 16 entries each in order,
-		// then (s0 + s1) + (s2 + s3).  Slots an op did not write hold stale values; their rows are never stored.
-		__builtin_amdgcn_wave_barrier();
-		double tot = 0.0;
-		if (my < NACC) {
-			const double *src = wave_cols + my * WCOL + seg * 16;
-			tot = src[0];
-#pragma unroll
-			for (int j = 1; j < 16; j++) tot += src[j];
-		}
-		tot += __shfl_xor(tot, 1, 64);
-		tot += __shfl_xor(tot, 2, 64);
-		__builtin_amdgcn_wave_barrier();
-		if (seg == 0 && my < NACC) {
-			int node = -1;  // accumulator -> gradient row (node id); -1 = unused for this op
-			switch (my) {
-				case 0: node = op->left; break;
-				case 1: node = op->right; break;
-				case 2: node = kl >= CH_CHERRY ? op->lt0 : -1; break;
-				case 3: node = kl >= CH_CHERRY ? op->lt1 : -1; break;
-				case 4: node = kl == CH_CHERRY_TIP ? op->linner : -1; break;
-				case 5: node = kl == CH_CHERRY_TIP ? op->lt2 : -1; break;
-				case 6: node = kr >= CH_CHERRY ? op->rt0 : -1; break;
-				case 7: node = kr >= CH_CHERRY ? op->rt1 : -1; break;
-				case 8: node = kr == CH_CHERRY_TIP ? op->rinner : -1; break;
-				case 9: node = kr == CH_CHERRY_TIP ? op->rt2 : -1; break;
-			}
-			if (node >= 0) gpart[((size_t)node * C + c) * nblk + slab] = tot;
-		}
-	}
-	if (PARAMS) {  // the 16 eigen-basis sums of this wave (all categories add into the same G_ab: one slab entry per wave)
-#pragma unroll
-		for (int a = 0; a < 16; a++) col[a * WCOL] = Gab[a];
-		__builtin_amdgcn_wave_barrier();
-		const double *src = wave_cols + my * WCOL + seg * 16;
-		double tot = src[0];
-#pragma unroll
-		for (int j = 1; j < 16; j++) tot += src[j];
-		tot += __shfl_xor(tot, 1, 64);
-		tot += __shfl_xor(tot, 2, 64);
-		if (seg == 0) gacc[(size_t)my * nblk * C + slab * C + c] = tot;
-	}
-}
-
-// G2 tables of the tree-walk kernel: Fw[n][c][a*4+b] = w_c F_ab(t_n r_c), F_ab = (e^{l_a t} - e^{l_b t}) / (l_a - l_b) or
-// t e^{l_a t} (dPdp_with_dQdp, substmodel.c:469-489); root and explicit-matrix nodes get zeros.  4 states.
-__global__ void k_eigen_weights(int C, int node_count, const double *__restrict__ model, const double *__restrict__ rates,
-                                const double *__restrict__ props, const double *__restrict__ lengths, const uint8_t *__restrict__ is_explicit, int root,
-                                double *__restrict__ Fw) {
-	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= node_count * C * 16) return;
-	const int b = idx & 3, a = (idx >> 2) & 3, c = (idx >> 4) % C, n = (idx >> 4) / C;
-	double v = 0.0;
-	if (n != root && !is_explicit[n]) {
-		const double t = lengths[n] * rates[c], la = model[a], lb = model[b], ea = exp(la * t);
-		v = props[c] * (la != lb ? (ea - exp(lb * t)) / (la - lb) : t * ea);
-	}
-	Fw[idx] = v;
-}
-
-// d lnL / d theta = sum_ab B_theta,ab G_ab (B = U^-1 dQ U, [np][16])
-__global__ void k_contract_parameters(int np, const double *__restrict__ B, const double *__restrict__ Gsum, double *__restrict__ out) {
-	const int th = blockIdx.x * blockDim.x + threadIdx.x;
-	if (th >= np) return;
-	double s = 0.0;
-	for (int ab = 0; ab < 16; ab++) s += B[(size_t)th * 16 + ab] * Gsum[ab];
-	out[th] = s;
-}
-
-// fixed-order reduction of per-block slabs: one wave per row. out[row_offset + row] = sum_b part[row][b]
-__global__ __launch_bounds__(64) void k_reduce_rows(const double *__restrict__ part, int nblk, const uint8_t *__restrict__ row_valid,
-                                                   double *__restrict__ out) {
-	const int row = blockIdx.x;
-	double s = 0.0;
-	if (row_valid == nullptr || row_valid[row]) {
-		for (int b = threadIdx.x; b < nblk; b += 64) s += part[(size_t)row * nblk + b];
-		s = wave_sum(s);
-	}
-	if (threadIdx.x == 0) out[row] = s;
-}
-
-// sum_k (w_k / L_k) sum_i pi_i ( p_root[0][k][i] - mean_{c >= 1} p_root[c][k][i] ): the d lnL / d(proportion of the
-// invariant class) term that needs the root partials (treelikelihood.c:2943-3008).  root: stored root partial;
-// cat_stride / pat_stride / state_stride describe its layout ([C][P][4] or planes [C][S][Pp]).
-__global__ __launch_bounds__(256) void k_root_invariant_term(int P, int S, int C, const double *__restrict__ root, size_t cat_stride, size_t pat_stride,
-                                                            size_t state_stride, const double *__restrict__ freqs,
-                                                            const double *__restrict__ w_over_L, double *__restrict__ part) {
-	__shared__ double red[4];
-	const int k = blockIdx.x * 256 + threadIdx.x;
-	double acc = 0.0;
-	if (k < P) {
-		double s = 0.0;
-		for (int i = 0; i < S; i++) {
-			const double *p = root + (size_t)k * pat_stride + (size_t)i * state_stride;
-			double others = 0.0;
-			for (int c = 1; c < C; c++) others += p[(size_t)c * cat_stride];
-			s += freqs[i] * (p[0] - others / (C - 1));
-		}
-		acc = s * w_over_L[k];
-	}
-	const double t = wave_sum(acc);
-	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
-	__syncthreads();
-	if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-// The root term of d lnL / d pi_f (calculate_dlnl_dQ, treelikelihood.c:2370-2401): for every state f
-//   sum_k w_k  ( sum_c w_c p_root[c][k][f] )  /  ( sum_i pi_i sum_c w_c p_root[c][k][i] ).
-// Scale factors are per pattern, so the same expression serves rescaled evaluations.  part: [S][gridDim.x]
-__global__ __launch_bounds__(256) void k_root_frequency_term(int P, int S, int C, const double *__restrict__ root, size_t cat_stride, size_t pat_stride,
-                                                            size_t state_stride, const double *__restrict__ freqs, const double *__restrict__ props,
-                                                            const double *__restrict__ weights, double *__restrict__ part) {
-	__shared__ double red[4];
-	const int k = blockIdx.x * 256 + threadIdx.x;
-	double like = 0.0;
-	if (k < P)
-		for (int i = 0; i < S; i++) {
-			const double *p = root + (size_t)k * pat_stride + (size_t)i * state_stride;
-			double m = 0.0;
-			for (int c = 0; c < C; c++) m += props[c] * p[(size_t)c * cat_stride];
-			like += freqs[i] * m;
-		}
-	const double wl = k < P ? weights[k] / like : 0.0;
-	for (int f = 0; f < S; f++) {
-		double m = 0.0;
-		if (k < P) {
-			const double *p = root + (size_t)k * pat_stride + (size_t)f * state_stride;
-			for (int c = 0; c < C; c++) m += props[c] * p[(size_t)c * cat_stride];
-		}
-		const double t = wave_sum(m * wl);
-		__syncthreads();
-		if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
-		__syncthreads();
-		if (threadIdx.x == 0) part[(size_t)f * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-	}
-}
-
+#include "phyamd_device.inc"
+#include "phyamd_level4.inc"
+#include "phyamd_walk4.inc"
 #include "phyamd_general.inc"
 
 }  // namespace
