@@ -150,6 +150,13 @@ int phyamd_parameter_gradient_device(phyamd_engine *e, int flags, double *device
 /* After an evaluation: out[f] = sum_k w_k (sum_c w_c p_root[c][k][f]) / (sum_i pi_i sum_c w_c p_root[c][k][i]), f < S:
  * d lnL / d pi_f through the root frequencies alone. */
 int phyamd_root_frequency_term(phyamd_engine *e, double *out /* [S] */);
+/* The optimiser's fast path (_calculate_uppper / dlnldt_uppper / d2lnldt2_uppper, treelikelihood.c:2196-2335, 2592-2686):
+ * lnL and its first two derivatives with respect to the length of ONE branch, evaluated at a TRIAL length from the upper
+ * and lower partials that meet on the branch -- O(patterns) work per trial instead of a tree sweep.  Needs
+ * phyamd_set_keep_partials(1) and a phyamd_gradient call for the current parameters (which leaves every upper partial
+ * resident); 4 states, unscaled evaluations.  Any of lnl / d1 / d2 may be NULL.  The engine's branch lengths are not
+ * changed: accept a length with phyamd_set_branch_length and re-evaluate. */
+int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, double *lnl, double *d1, double *d2);
 int phyamd_synchronize(phyamd_engine *e);
 
 /* --- inspection (parity tests, debugging) --- */

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("phyamd_parameter_gradient", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), _P, _P]),
     ("phyamd_parameter_gradient_device", C.c_int, [_P, C.c_int, _P]),
     ("phyamd_root_frequency_term", C.c_int, [_P, _P]),
+    ("phyamd_branch_log_likelihood", C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("phyamd_synchronize", C.c_int, [_P]),
     ("phyamd_get_pattern_log_likelihoods", C.c_int, [_P, _P]),
     ("phyamd_get_partials", C.c_int, [_P, C.c_int, C.c_int, _P]),

@@ -176,6 +176,8 @@ struct phyamd_engine {
 	double *d_pbuf = nullptr;        // tree-walk G2: [UTpi 16 | Uinv 16 | utab 64]
 	double *d_Fw = nullptr;          // tree-walk G2: [N][C][16] w_c F_ab(t_n r_c)
 	double *d_gacc = nullptr;        // tree-walk G2: [16][slabs * C] per-wave eigen-basis sums, then [16] totals
+	double *d_branch = nullptr;      // phyamd_branch_log_likelihood: [C][3][16] matrices | [3][blocks] partial sums | [3]
+	bool upper_fold = false;         // the stored uppers carry the root frequencies (last gradient call used FOLD)
 	double *d_rf_part = nullptr;     // [S][blocks] partial sums of k_root_frequency_term, then [S]
 	double *d_gen_scratch = nullptr; // rescaled S != 4 path: per-level maxima / numerators / denominators
 	size_t gen_scratch_alloc = 0;
@@ -1013,6 +1015,7 @@ int launch_root_frequency_term(phyamd_engine *e, double *dst) {
 
 int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 	int rc;
+	e->upper_fold = (flags & PHYAMD_GRAD_FOLD_ROOT_FREQS) != 0;
 	if (with_params) {
 		if (e->generic) return fail(PHYAMD_EUNSUPPORTED, "substitution-parameter gradients are built for 4-state models only");
 		if (e->np < 1) return fail(PHYAMD_EINVAL, "phyamd_set_rate_matrix_derivatives has not been called");
@@ -1217,7 +1220,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops, (void *)e->d_Qpi})
@@ -1564,6 +1567,56 @@ int phyamd_root_frequency_term(phyamd_engine *e, double *out) {
 	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_rf_part + (size_t)((e->P + 255) / 256) * e->S, sizeof(double) * e->S, hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	std::memcpy(out, e->h_result, sizeof(double) * e->S);
+	return PHYAMD_OK;
+}
+
+int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, double *lnl, double *d1, double *d2) {
+	CHECK_ENGINE(e);
+	if (e->generic) return fail(PHYAMD_EUNSUPPORTED, "the single-branch evaluation is built for 4-state models");
+	if (e->scaling_on) return fail(PHYAMD_EUNSUPPORTED, "the single-branch evaluation is not built for rescaled evaluations (upper scale factors are not kept)");
+	if (node < 0 || node >= e->N || node == e->root) return fail(PHYAMD_EINVAL, "node %d has no branch", node);
+	if (!e->keep_partials || !e->upper_valid)
+		return fail(PHYAMD_EINVAL, "the single-branch evaluation needs the partials of phyamd_gradient with phyamd_set_keep_partials(1)");
+	if (!e->have_eigen) return fail(PHYAMD_EINVAL, "the single-branch evaluation needs the eigen system (phyamd_set_eigen)");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	const int C = e->C, nb = (e->P + WAVE - 1) / WAVE;
+	const size_t need = (size_t)C * 48 + (size_t)3 * nb + 3;
+	if (!e->d_branch && (rc = dev_alloc(e, &e->d_branch, need))) return rc;
+	// P(t r_c), r_c Q P, r_c^2 Q Q P from the eigen system (4x4, host)
+	const double *ev = e->model.data(), *U = ev + 4, *Ui = U + 16;
+	std::vector<double> pm((size_t)C * 48);
+	for (int c = 0; c < C; c++) {
+		const double r = e->rates[c], t = length * r;
+		for (int i = 0; i < 4; i++)
+			for (int j = 0; j < 4; j++) {
+				double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+				for (int a = 0; a < 4; a++) {
+					const double w = U[i * 4 + a] * Ui[a * 4 + j], ex = std::exp(ev[a] * t);
+					p0 += w * ex;
+					p1 += w * ev[a] * ex;
+					p2 += w * ev[a] * ev[a] * ex;
+				}
+				pm[(size_t)c * 48 + i * 4 + j] = std::fabs(p0);  // substmodel.c:552
+				pm[(size_t)c * 48 + 16 + i * 4 + j] = r * p1;
+				pm[(size_t)c * 48 + 32 + i * 4 + j] = r * r * p2;
+			}
+	}
+	HIP_TRY(hipMemcpyAsync(e->d_branch, pm.data(), sizeof(double) * pm.size(), hipMemcpyHostToDevice, e->stream));
+	const size_t npd = node_partial_doubles(e);
+	const double *up = e->d_upper + (size_t)e->upper_slot[node] * npd;
+	const double *low = node < e->T ? nullptr : e->d_lower + (size_t)e->core_index[node] * npd;
+	double *part = e->d_branch + (size_t)C * 48;
+	hipLaunchKernelGGL(k_branch_eval4, dim3(nb), dim3(WAVE, C), sizeof(double) * 3 * C * WAVE, e->stream, e->P, C, up, low,
+	                   node < e->T ? e->d_tipmask + (size_t)node * e->P : (const uint8_t *)nullptr, e->d_branch, e->d_freqs, e->upper_fold ? 1 : 0, e->d_props,
+	                   e->d_weights, part);
+	hipLaunchKernelGGL(k_reduce_rows, dim3(3), dim3(64), 0, e->stream, part, nb, (const uint8_t *)nullptr, part + (size_t)3 * nb);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(e->h_result, part + (size_t)3 * nb, sizeof(double) * 3, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));  // also covers pm (stack-lifetime buffer)
+	if (lnl) *lnl = e->h_result[0];
+	if (d1) *d1 = e->h_result[1];
+	if (d2) *d2 = e->h_result[2];
 	return PHYAMD_OK;
 }
 

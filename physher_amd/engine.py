@@ -164,6 +164,13 @@ class Engine:
         self._check(self._lib.phyamd_root_frequency_term(self._h, _ptr(a)))
         return a
 
+    def branch_log_likelihood(self, node, length):
+        """(lnL, d lnL/dt, d2 lnL/dt2) of one branch at a trial length, from the resident upper/lower partials
+        (needs set_keep_partials(True) and a gradient() call for the current parameters)."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.phyamd_branch_log_likelihood(self._h, int(node), float(length), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def synchronize(self):
         self._check(self._lib.phyamd_synchronize(self._h))
 

@@ -595,3 +595,46 @@ def test_single_branch_updates_recompute_only_the_path_to_the_root(S, T, P, C, r
         e.update_all_nodes()
         assert abs(e.log_likelihood() - orc["lnl"]) <= 1e-10 * abs(orc["lnl"])
         assert e.profile()["lower_launches"] >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# f.2: the optimiser's fast path -- lnL and two derivatives along ONE branch from the resident partials
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,P,C,fold", [(20, 333, 4, 0), (9, 64, 1, 0), (14, 100, 3, 1)])
+def test_single_branch_evaluation(T, P, C, fold):
+    """phyamd_branch_log_likelihood against full recomputations: lnL(t) for trial lengths of tip and internal branches,
+    d1 against the branch gradient and central differences, d2 against central differences of d1
+    (_calculate_uppper / dlnldt_uppper / d2lnldt2_uppper, treelikelihood.c:2196-2335, 2592-2686)."""
+    pb = random_problem(T, P, C, seed=60 + T, gaps=0.03, fold_root_freqs=fold)
+    flags = GRAD_FOLD_ROOT_FREQS if fold else 0
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e, engine_from_problem(pb, rescale=RESCALE_NEVER) as full:
+        with pytest.raises(EngineError):
+            e.branch_log_likelihood(0, 0.1)  # partials are not resident yet
+        e.set_keep_partials(True)
+        lnl0, cg = e.gradient(flags)
+        bg = po.branch_gradient_from_cat(cg, pb.cat_rates, pb.cat_props)
+        rng = np.random.default_rng(1)
+        nodes = [0, T - 1] + list(rng.choice([n for n in range(T, pb.N) if n != pb.root], size=3, replace=False))
+        for n in nodes:
+            t0 = pb.branch_lengths[n]
+            l, d1, d2 = e.branch_log_likelihood(n, t0)
+            if not fold:  # (the folded form is the reference's inexact arithmetic for non-uniform pi: only self-consistency below)
+                assert abs(l - lnl0) <= 1e-11 * abs(lnl0)
+                assert abs(d1 - bg[n]) <= 1e-9 * max(1.0, abs(bg[n]))
+            for t in (0.5 * t0, 1.7 * t0, 0.3):
+                lt, d1t, d2t = e.branch_log_likelihood(n, t)
+                if not fold:
+                    bl = pb.branch_lengths.copy()
+                    bl[n] = t
+                    full.set_branch_lengths(bl)
+                    assert abs(lt - full.log_likelihood()) <= 1e-11 * abs(lt)
+                h = 1e-5 * max(t, 1e-3)
+                lp, d1p, _ = e.branch_log_likelihood(n, t + h)
+                lm, d1m, _ = e.branch_log_likelihood(n, t - h)
+                assert abs((lp - lm) / (2 * h) - d1t) <= 1e-5 * max(1.0, abs(d1t))
+                assert abs((d1p - d1m) / (2 * h) - d2t) <= 1e-5 * max(1.0, abs(d2t))
+        with pytest.raises(EngineError):
+            e.branch_log_likelihood(pb.root, 0.1)
+        e.set_branch_length(0, 0.5)  # the partials no longer belong to the parameters
+        with pytest.raises(EngineError):
+            e.branch_log_likelihood(0, 0.5)
