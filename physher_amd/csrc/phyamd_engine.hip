@@ -70,7 +70,16 @@ constexpr int PPT_LOWER = PHYAMD_PPT_LOWER, PPT_UPPER = PHYAMD_PPT_UPPER;
 constexpr int MAX_WAVES = 16;        // 1024 threads
 constexpr double SCALING_THRESHOLD = 1.0e-40;  // treelikelihood.c:1121
 
-enum { CH_TIP = 0, CH_CORE = 1, CH_CHERRY = 2, CH_CHERRY_TIP = 3 };  // how a child's lower partial is obtained
+// how a child's lower partial is obtained: read (CORE), or recomputed in registers from tips (CHERRY, CHERRY_TIP: "fringe",
+// which also has its inner branch gradients computed inside its parent's pre-order op) or from two fringe / tip children
+// (DEEP: no stored lower either, but a pre-order op of its own)
+enum { CH_TIP = 0, CH_CORE = 1, CH_DEEP = 2, CH_CHERRY = 3, CH_CHERRY_TIP = 4 };
+
+// children of a DEEP node, by node id: what child_message needs to rebuild its partial
+struct DeepDesc {
+	int32_t kind_left, left, lt0, lt1, lt2, linner;
+	int32_t kind_right, right, rt0, rt1, rt2, rinner;
+};
 
 struct NodeOp {
 	int32_t parent;  // lower pass: destination node; upper pass: the node whose children are produced
@@ -154,6 +163,10 @@ struct phyamd_engine {
 	std::vector<int32_t> core_index;  // node -> index of its stored lower array (-1: tip or fused)
 	int core_count = 0;
 	bool fusion_enabled = true, fused = false;
+	bool deep_enabled = true;          // PHYAMD_DEEP = 0: every node above the fringe is stored
+	std::vector<DeepDesc> deep_host;   // by node id (only DEEP nodes filled)
+	int deep_count = 0;
+	// (device copy: behind the tip-message table, see Ctx4::deep)
 	size_t lower_alloc_cores = 0;
 
 	// device memory
@@ -271,6 +284,8 @@ int build_schedule(phyamd_engine *e) {
 			const int l = e->left[n], r = e->right[n];
 			if (l < T && r < T) kind[n] = CH_CHERRY;
 			else if ((l < T && kind[r] == CH_CHERRY) || (r < T && kind[l] == CH_CHERRY)) kind[n] = CH_CHERRY_TIP;
+			else if (e->deep_enabled && kind[l] != CH_CORE && kind[l] != CH_DEEP && kind[r] != CH_CORE && kind[r] != CH_DEEP)
+				kind[n] = CH_DEEP;  // both children are tips or fringe: 4-6 tips below, rebuilt in registers wherever its partial is needed
 		}
 	}
 	// stored lower arrays: core nodes in id order
@@ -293,6 +308,18 @@ int build_schedule(phyamd_engine *e) {
 			t1 = e->right[inner];
 		}
 	};
+	e->deep_host.assign(N, DeepDesc{});
+	e->deep_count = 0;
+	for (int n = T; n < N; n++)
+		if (kind[n] == CH_DEEP) {
+			DeepDesc &d = e->deep_host[n];
+			int32_t core_unused;
+			d.left = e->left[n];
+			d.right = e->right[n];
+			describe(d.left, d.kind_left, core_unused, d.lt0, d.lt1, d.lt2, d.linner);
+			describe(d.right, d.kind_right, core_unused, d.rt0, d.rt1, d.rt2, d.rinner);
+			e->deep_count++;
+		}
 	auto make_op = [&](int n) {
 		NodeOp op{};
 		op.parent = n;
@@ -335,12 +362,12 @@ int build_schedule(phyamd_engine *e) {
 			slots_of_depth[d - 1].clear();
 		}
 		for (int n = T; n < N; n++) {
-			if (depth[n] != d || kind[n] != CH_CORE) continue;
+			if (depth[n] != d || (kind[n] != CH_CORE && kind[n] != CH_DEEP)) continue;
 			NodeOp op = make_op(n);
 			op.upper_slot_parent = n == e->root ? -1 : e->upper_slot[n];
 			for (int side = 0; side < 2; side++) {
 				const int ch = side ? e->right[n] : e->left[n];
-				if (kind[ch] != CH_CORE && !e->keep_partials) continue;  // uppers of tips and fused nodes stay in registers
+				if (kind[ch] != CH_CORE && kind[ch] != CH_DEEP && !e->keep_partials) continue;  // uppers of tips and fringe nodes stay in registers
 				int s;
 				if (e->keep_partials) s = ch;
 				else if (!free_slots.empty()) {
@@ -364,10 +391,11 @@ int build_schedule(phyamd_engine *e) {
 	e->walk_upper_ops.clear();
 	e->walk_upper_slots = 0;
 	if (e->walking) {
-		std::vector<int> csize(N, 0);
+		std::vector<int> csize(N, 0), usize(N, 0);  // stored nodes / pre-order ops (stored + DEEP) in the subtree
 		for (int i = N - 1; i >= 0; i--) {
 			const int n = order[i];
 			if (kind[n] == CH_CORE) csize[n] = 1 + csize[e->left[n]] + csize[e->right[n]];
+			if (kind[n] == CH_CORE || kind[n] == CH_DEEP) usize[n] = 1 + usize[e->left[n]] + usize[e->right[n]];
 		}
 		// post-order, larger core subtree first: the op before a node is its second (smaller) core child, or its only one
 		struct Frame {
@@ -414,10 +442,10 @@ int build_schedule(phyamd_engine *e) {
 				free_w.push_back(slot_of[n]);  // read by this op; reusable by ops after it
 			}
 			const int l = e->left[n], r = e->right[n];
-			const bool lc = kind[l] == CH_CORE, rc2 = kind[r] == CH_CORE;
+			const bool lc = kind[l] == CH_CORE || kind[l] == CH_DEEP, rc2 = kind[r] == CH_CORE || kind[r] == CH_DEEP;  // children with ops of their own
 			int first = -1, second = -1;
 			if (lc && rc2) {
-				first = csize[l] <= csize[r] ? l : r;
+				first = usize[l] <= usize[r] ? l : r;
 				second = first == l ? r : l;
 			} else if (lc || rc2)
 				first = lc ? l : r;
@@ -465,6 +493,10 @@ int upload_schedule(phyamd_engine *e) {
 	if (!e->d_upper_ops && (rc = dev_alloc(e, &e->d_upper_ops, (size_t)e->N))) return rc;
 	HIP_TRY(hipMemcpyAsync(e->d_lower_ops, e->lower_ops.data(), e->lower_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipMemcpyAsync(e->d_upper_ops, e->upper_ops.data(), e->upper_ops.size() * sizeof(NodeOp), hipMemcpyHostToDevice, e->stream));
+	static_assert(sizeof(DeepDesc) == 6 * sizeof(double), "DeepDesc is laid out in the tail of the tip-message table");
+	if (!e->generic)
+		HIP_TRY(hipMemcpyAsync(e->d_tiptab + (size_t)e->T * e->C * 64, e->deep_host.data(), e->deep_host.size() * sizeof(DeepDesc), hipMemcpyHostToDevice,
+		                       e->stream));
 	if (e->walking) {
 		if (!e->d_walk_lower_ops && (rc = dev_alloc(e, &e->d_walk_lower_ops, (size_t)e->N))) return rc;
 		if (!e->d_walk_upper_ops && (rc = dev_alloc(e, &e->d_walk_upper_ops, (size_t)e->N))) return rc;
@@ -1139,6 +1171,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	}
 	e->scaling_on = cfg->rescale == PHYAMD_RESCALE_ALWAYS;
 	if (const char *env = std::getenv("PHYAMD_FUSE")) e->fusion_enabled = std::atoi(env) != 0;  // A/B switch for the fringe fusion
+	if (const char *env = std::getenv("PHYAMD_DEEP")) e->deep_enabled = std::atoi(env) != 0;
 	if (e->C > MAX_WAVES) {
 		delete e;
 		return fail(PHYAMD_EUNSUPPORTED, "category_count %d exceeds %d (one wave per category)", cfg->category_count, MAX_WAVES);
@@ -1185,7 +1218,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	if ((rc = dev_alloc(e, &e->d_dmats, msz))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_model, (size_t)e->S + 2 * e->S * e->S))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_Q, (size_t)e->S * e->S))) return bail(rc);
-	if (!e->generic && (rc = dev_alloc(e, &e->d_tiptab, (size_t)e->T * e->C * 64))) return bail(rc);
+	if (!e->generic && (rc = dev_alloc(e, &e->d_tiptab, (size_t)e->T * e->C * 64 + (size_t)e->N * 6))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_freqs, (size_t)e->S))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_rates, (size_t)e->C))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_props, (size_t)e->C))) return bail(rc);
