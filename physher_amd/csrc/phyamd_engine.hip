@@ -592,17 +592,18 @@ int launch_lower_levels(phyamd_engine *e) {
 	return PHYAMD_OK;
 }
 
+template <int WAVES, bool SCALE, int PPT>
+void launch_lower_walk_ppt(phyamd_engine *e, size_t lds) {
+	hipLaunchKernelGGL((k_lower4_walk<WAVES, PPT, SCALE>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(), e->T,
+	                   e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
+	                   e->d_lnl_part);
+}
+
 template <int WAVES, bool SCALE>
 int launch_lower_walk(phyamd_engine *e) {
 	const size_t lds = sizeof(double) * ((size_t)e->G * e->C * WAVE * (SCALE ? 3 : 1) + e->G);
-	if (e->ppt_walk_lower == 1)
-		hipLaunchKernelGGL((k_lower4_walk<WAVES, 1, SCALE>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(),
-		                   e->T, e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
-		                   e->d_lnl_part);
-	else
-		hipLaunchKernelGGL((k_lower4_walk<WAVES, 2, SCALE>), dim3(e->nblk_walk), block_dims(e), lds, e->stream, e->d_walk_lower_ops, (int)e->walk_lower_ops.size(),
-		                   e->T, e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats, e->d_tiptab, e->d_lscale, e->d_freqs, e->d_props, e->d_weights, e->d_plk, e->d_wl,
-		                   e->d_lnl_part);
+	if (e->ppt_walk_lower == 1) launch_lower_walk_ppt<WAVES, SCALE, 1>(e, lds);
+	else launch_lower_walk_ppt<WAVES, SCALE, 2>(e, lds);
 	HIP_TRY(hipGetLastError());
 	e->prof.lower_launches = 1;
 	e->lnl_blocks = e->nblk_walk;
@@ -1181,10 +1182,9 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	e->nblk_lower = (e->P + WAVE * e->G * PPT_LOWER - 1) / (WAVE * e->G * PPT_LOWER);  // post-order kernel / lnL slab
 	{
 		// Tree-walk geometry.  The pre-order walk always takes one pattern per thread (see k_upper4_walk); the post-order walk
-		// is write-bound and prefers one pattern per thread once the shard fills the chip, two below that (measured on
-		// 125k..1M-pattern shards).  PHYAMD_PPT_WALK_LOWER overrides (A/B runs).
+		// two (measured on 125k..1M-pattern shards: 1 and 4 are 5-10 % slower).  PHYAMD_PPT_WALK_LOWER = 1 overrides (A/B runs).
 		const int groups = (e->P + WAVE * e->G - 1) / (WAVE * e->G);  // workgroups at one pattern per thread
-		e->ppt_walk_lower = groups >= 3000 ? 1 : 2;
+		e->ppt_walk_lower = 2;
 		if (const char *env = std::getenv("PHYAMD_PPT_WALK_LOWER")) e->ppt_walk_lower = std::atoi(env) == 1 ? 1 : 2;
 		e->nblk_walk = (groups + e->ppt_walk_lower - 1) / e->ppt_walk_lower;
 		e->nblk_walk_upper = groups;
