@@ -132,9 +132,10 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
                 f.write(f"fasta {d}/aln.fa\nnewick {d}/tree.nwk\ndatatype nucleotide\nmodel gtr\n"
                         f"rates {','.join(map(str, GTR_RATES[:5]))}\nfreqs {','.join(map(str, GTR_FREQS))}\n"
                         f"categories {len(cat_rates)}\nalpha {ALPHA}\ntipstates 0\nsse 1\n")
-            # one gradient evaluation costs ~26 ns per (branch, pattern, category) on a 2 GHz core
-            est = 26e-9 * (2 * T - 2) * sp * len(cat_rates) * 1.3
-            iters = max(1, min(10, int(budget_s / (2.5 * est))))
+            # one gradient evaluation costs 16-26 ns per (branch, pattern, category) per core; the driver also times as many
+            # lnL-only evaluations (~40 % of that) and one warm-up of each
+            est = 20e-9 * (2 * T - 2) * sp * len(cat_rates)
+            iters = max(3, min(40, int(budget_s / (1.5 * est))))
             try:
                 out = subprocess.run([driver, "bench", os.path.join(d, "spec.txt"), str(iters), "1"], capture_output=True, text=True,
                                      timeout=max(120, 20 * budget_s), check=True).stdout
@@ -167,7 +168,7 @@ def main():
     ap.add_argument("--patterns", type=int, default=None)
     ap.add_argument("--categories", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-sample-patterns", type=int, default=2000)
+    ap.add_argument("--cpu-sample-patterns", type=int, default=8000)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rescale", choices=("auto", "always", "never"), default="auto",
