@@ -125,7 +125,7 @@ int phyamd_branch_gradient(phyamd_engine *e, int flags, const double *rates_with
 /* Device-resident result for multi-GPU sharding: writes [lnL, g[0][0..C-1], g[1][..], ...]
  * (1 + (2T-1)*C doubles) to `device_out` on the engine's stream, no host synchronisation. */
 int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out);
-/* After an (unscaled) evaluation: sum_k (w_k / L_k) sum_i pi_i ( p_root[cat 0] - mean of p_root[cat >= 1] ), the only part
+/* After an evaluation (rescaled or not): sum_k (w_k / L_k) sum_i pi_i ( p_root[cat 0] - mean of p_root[cat >= 1] ), the only part
  * of the +I site-model gradient that needs O(P) data (gradient_pinv_sitemodel / gradient_pinv_W_sitemodel,
  * treelikelihood.c:2943-3008); the rest of that gradient is O(N C) host arithmetic on phyamd_gradient's output. */
 int phyamd_root_invariant_term(phyamd_engine *e, double *out);

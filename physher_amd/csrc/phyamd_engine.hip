@@ -1657,7 +1657,6 @@ int phyamd_root_invariant_term(phyamd_engine *e, double *out) {
 	CHECK_ENGINE(e);
 	if (!out) return fail(PHYAMD_EINVAL, "null out");
 	if (e->C < 2) return fail(PHYAMD_EINVAL, "the invariant-class term needs at least two categories");
-	if (e->scaling_on) return fail(PHYAMD_EUNSUPPORTED, "the invariant-class term is not built for rescaled evaluations");
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	if ((rc = check_ready(e))) return rc;
@@ -1667,7 +1666,7 @@ int phyamd_root_invariant_term(phyamd_engine *e, double *out) {
 	const size_t cat_stride = e->generic ? (size_t)e->S * e->Pp : (size_t)e->P * e->S;
 	const size_t pat_stride = e->generic ? 1 : (size_t)e->S, state_stride = e->generic ? (size_t)e->Pp : 1;
 	hipLaunchKernelGGL(k_root_invariant_term, dim3(nb), dim3(256), 0, e->stream, e->P, e->S, e->C, root, cat_stride, pat_stride, state_stride, e->d_freqs,
-	                   e->d_wl, e->d_inv_part);
+	                   e->d_props, e->d_weights, e->d_inv_part);
 	hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_inv_part, nb, (const uint8_t *)nullptr, e->d_inv_part + nb);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_inv_part + nb, sizeof(double), hipMemcpyDeviceToHost, e->stream));

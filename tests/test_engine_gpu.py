@@ -638,3 +638,14 @@ def test_single_branch_evaluation(T, P, C, fold):
         e.set_branch_length(0, 0.5)  # the partials no longer belong to the parameters
         with pytest.raises(EngineError):
             e.branch_log_likelihood(0, 0.5)
+
+
+def test_root_terms_agree_between_rescaled_and_unscaled_evaluations():
+    """The +I root term and the frequency root term form L_k from the root partial itself, so they are the same numbers
+    whether the evaluation was rescaled or not."""
+    pb = random_problem(40, 300, 4, seed=77, gaps=0.02)
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as a, engine_from_problem(pb, rescale=RESCALE_ALWAYS) as b:
+        la, lb = a.log_likelihood(), b.log_likelihood()
+        assert b.rescaling and abs(la - lb) <= 1e-11 * abs(la)
+        assert abs(a.root_invariant_term() - b.root_invariant_term()) <= 1e-10 * max(1.0, abs(a.root_invariant_term()))
+        np.testing.assert_allclose(a.root_frequency_term(), b.root_frequency_term(), rtol=1e-10)
