@@ -449,6 +449,18 @@ int main(int argc, char **argv) {
 		tlk->include_jacobian = false;
 		SingleTreeLikelihood_update_all_nodes(tlk);
 		{
+			/* every block the model can differentiate: [tree (ratios / root height)][site model][clock][substitution model] */
+			int flags = TREELIKELIHOOD_FLAG_TREE_MODEL | TREELIKELIHOOD_FLAG_BRANCH_MODEL;
+			if (tlk->sm->proportions != NULL || Parameters_count(tlk->sm->rates) > 0 || tlk->sm->mu != NULL) flags |= TREELIKELIHOOD_FLAG_SITE_MODEL;
+			if (tlk->m->dPdp != NULL) flags |= TREELIKELIHOOD_FLAG_SUBSTITUTION_MODEL;
+			size_t len = TreeLikelihood_initialize_gradient(model, flags);
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			double *g = TreeLikelihood_gradient(model);
+			jarr(o, "gradient_all_time", g, len, true);
+			fprintf(o, "\"gradient_all_time_flags\":%d,\n", flags);
+			SingleTreeLikelihood_update_all_nodes(tlk);
+		}
+		{
 			Tree *tree = tlk->tree;
 			int N = Tree_node_count(tree);
 			double *h = malloc(sizeof(double) * N), *bl = malloc(sizeof(double) * N);

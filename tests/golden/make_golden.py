@@ -130,6 +130,41 @@ def run_fluA():
           f"lnL+jac={data['lnl_jacobian1']!r} (-4786.867701371271)")
 
 
+def run_fluA_hky_g4():
+    """The fluA time tree (data fixture of fluA_jc69_time) under HKY + G4 with a strict clock: a configuration of ours in the
+    reference's JSON schema, run through the driver's json mode -- pins the ratio / clock / site / substitution blocks of
+    the time-tree gradient beyond the reference's own JC69 test."""
+    src = os.path.join(HERE, "fluA_jc69_time")
+    d = os.path.join(HERE, "fluA_hky_g4_time")
+    os.makedirs(d, exist_ok=True)
+    shutil.copyfile(os.path.join(src, "fluA.fa"), os.path.join(d, "fluA.fa"))
+    with open(os.path.join(src, "jc69-time.json")) as f:
+        js = json.load(f)
+    model = js["model"]
+    model["sitemodel"]["substitutionmodel"] = {
+        "id": "sm", "type": "substitutionmodel", "model": "hky", "datatype": "nucleotide",
+        "frequencies": {"id": "freqs", "type": "Simplex", "values": [0.33, 0.19, 0.23, 0.25]},
+        "rates": {"kappa": {"id": "kappa", "type": "parameter", "value": 3.0, "lower": 0, "upper": "infinity"}},
+    }
+    model["sitemodel"]["distribution"] = {
+        "distribution": "gamma", "categories": 4,
+        "parameters": {"alpha": {"id": "alpha", "type": "parameter", "value": 0.6, "lower": 0, "upper": "infinity"}},
+    }
+    model["branchmodel"]["rate"]["value"] = 0.0015
+    with open(os.path.join(d, "hky-g4-time.json"), "w") as f:
+        json.dump({"model": model}, f, indent=1)
+    out = os.path.join(d, "expected.json")
+    subprocess.check_call([DRIVER, "json", "hky-g4-time.json", out], cwd=d, stdout=subprocess.DEVNULL)
+    with open(out) as f:
+        data = json.load(f)
+    os.remove(out)
+    for k in SLIM_DROP:
+        data.pop(k, None)
+    with gzip.GzipFile(out + ".gz", "w", mtime=0) as f:
+        f.write(json.dumps(data, separators=(",", ":")).encode())
+    print(f"fluA_hky_g4_time: lnL={data['lnl_jacobian0']!r}, gradient blocks={len(data['gradient_all_time'])} flags={data['gradient_all_time_flags']}")
+
+
 if __name__ == "__main__":
     build_ref()
     only = sys.argv[1:]
@@ -138,3 +173,5 @@ if __name__ == "__main__":
             run_case(name, opts)
     if not only or "fluA_jc69_time" in only:
         run_fluA()
+    if not only or "fluA_hky_g4_time" in only:
+        run_fluA_hky_g4()

@@ -360,3 +360,43 @@ def test_attribute_patterns_with_ambiguity_sets():
                     tip_states=np.zeros((T, 1), dtype=np.uint8), tip_partials=tp)
     ref = pb.log_likelihood()
     assert abs(tlk.log_likelihood() - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+
+
+def test_fluA_time_tree_hky_gamma_all_gradient_blocks():
+    """Time tree + strict clock + HKY + G4 on the fluA data (fixture generated from the compiled reference by
+    tests/golden/make_golden.py::run_fluA_hky_g4): lnL and the whole gradient -- 68 ratio / root-height entries, gamma shape,
+    clock rate, kappa and the four frequencies -- in the reference's order (treelikelihood.c:3205-3361)."""
+    from physher_amd import _phycpp_amd as pc
+    F = pc.TreeLikelihoodGradientFlags
+    d = os.path.join(GOLDEN, "fluA_hky_g4_time")
+    with open(os.path.join(d, "hky-g4-time.json")) as f:
+        js = json.load(f)["model"]
+    gold = load("fluA_hky_g4_time")
+    names, seqs = read_fasta(os.path.join(d, "fluA.fa"))
+    dates = [float(js["tree"]["dates"][t]) for t in names]
+    tree = pc.ReparameterizedTimeTreeModelInterface(js["tree"]["newick"], names, dates, pc.TreeTransformFlags.RATIO)
+    clock = pc.StrictClockModelInterface(js["branchmodel"]["rate"]["value"], tree)
+    sm = js["sitemodel"]["substitutionmodel"]
+    subst = pc.HKYInterface(sm["rates"]["kappa"]["value"], sm["frequencies"]["values"])
+    site = pc.GammaSiteModelInterface(js["sitemodel"]["distribution"]["parameters"]["alpha"]["value"], 4, None, None)
+    tlk = pc.TreeLikelihoodInterface(list(zip(names, seqs)), tree, subst, site, clock, use_tip_states=True, include_jacobian=False)
+    lnl = tlk.log_likelihood()
+    assert abs(lnl - gold["lnl_jacobian0"]) <= 1e-10 * abs(lnl)
+    ref = np.array(gold["gradient_all_time"])
+    assert gold["gradient_all_time_flags"] == 1 | 2 | 4 | 64 and len(ref) == 68 + 1 + 1 + 5
+    tlk.request_gradient([F.TREE_HEIGHT, F.SITE_MODEL, F.BRANCH_MODEL, F.SUBSTITUTION_MODEL])
+    assert tlk.gradient_length == len(ref)
+    g = tlk.gradient()
+    assert np.abs(g[:68] - ref[:68]).max() <= 1e-9 * np.abs(ref[:68]).max()            # ratios, root height
+    assert abs(g[68] - ref[68]) <= 2e-7 * max(1.0, abs(ref[68]))                          # gamma shape (the reference's own central difference)
+    assert abs(g[69] - ref[69]) <= 1e-9 * abs(ref[69])                                    # clock rate
+    np.testing.assert_allclose(g[70:], ref[70:], rtol=2e-8, atol=1e-7)                   # kappa, frequencies
+    # the jacobian variant of lnL and of the tree block, as in the reference's test for JC69
+    tree2 = pc.ReparameterizedTimeTreeModelInterface(js["tree"]["newick"], names, dates, pc.TreeTransformFlags.RATIO)
+    clock2 = pc.StrictClockModelInterface(js["branchmodel"]["rate"]["value"], tree2)
+    tlk2 = pc.TreeLikelihoodInterface(list(zip(names, seqs)), tree2, subst, site, clock2, use_tip_states=True, include_jacobian=True)
+    assert abs(tlk2.log_likelihood() - gold["lnl_jacobian1"]) <= 1e-10 * abs(gold["lnl_jacobian1"])
+    tlk2.request_gradient([F.TREE_HEIGHT, F.BRANCH_MODEL])
+    tlk2.set_reference_compatibility(True)  # tree + clock only: the reference folds the root frequencies (inexact for this pi)
+    ref1 = np.array(gold["gradient_tree_clock_jacobian1"])
+    assert np.abs(tlk2.gradient() - ref1).max() <= 1e-9 * np.abs(ref1).max()
