@@ -78,8 +78,10 @@ int phyamd_abi_version(void);
 /* --- data: sp->patterns / sp->weights / tlk->partials of tips (sitepattern.h:68-82, treelikelihood.c:1106-1117) --- */
 /* states[P] codes of one tip ("tipstates": true semantics; code >= S => all ones). */
 int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states);
-/* partials[P][S] of one tip ("tipstates": false semantics: ambiguity masks or any likelihood vector);
- * replicated over categories like treelikelihood.c:1111-1114. */
+/* partials[P][S] of one tip ("tipstates": false semantics), replicated over categories like treelikelihood.c:1111-1114.
+ * Built for the 0/1 vectors every data type of the reference produces (datatype.c:212-240, datatype.h:26-66): one state,
+ * all states, or a set of states (nucleotide ambiguity codes; named sets of a general data type -- at most 255 - S
+ * distinct sets per engine for 20 / 60 / 61 states); other values are refused with PHYAMD_EUNSUPPORTED. */
 int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials);
 int phyamd_set_pattern_weights(phyamd_engine *e, const double *weights /* [P] */);
 
@@ -130,7 +132,7 @@ int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out);
  * treelikelihood.c:2943-3008); the rest of that gradient is O(N C) host arithmetic on phyamd_gradient's output. */
 int phyamd_root_invariant_term(phyamd_engine *e, double *out);
 
-/* --- substitution-model gradient (4-state models): calculate_dlnl_dQ (treelikelihood.c:2337-2583) --- */
+/* --- substitution-model gradient: calculate_dlnl_dQ (treelikelihood.c:2337-2583) --- */
 #define PHYAMD_MAX_PARAMETERS 64
 /* dQ [count][S][S]: derivative of the (normalised) rate matrix with respect to each parameter, what the reference's
  * m->dQ holds after _gtr_dQdp / _hky_dQdp / _general_dQdp (gtr.c:256-326, hky.c:493-541, gensubst.c:216-279).  The engine
@@ -141,7 +143,10 @@ int phyamd_set_rate_matrix_derivatives(phyamd_engine *e, int count, const double
  *   parameter_gradient[th] = sum_k (w_k / L_k) sum_branches sum_c w_c sum_i pi_i u_i (dP_th p)_i
  * i.e. the branch sum of calculate_dlnl_dQ for all parameters at once (the reference re-walks the tree per parameter).
  * For a frequency parameter add dpi_f/dtheta * phyamd_root_frequency_term()[f] (treelikelihood.c:2370-2401).
- * Works with rescaling; PHYAMD_GRAD_FOLD_ROOT_FREQS is refused (the reference clears include_root_freqs here). */
+ * Works with rescaling; PHYAMD_GRAD_FOLD_ROOT_FREQS is refused (the reference clears include_root_freqs here).
+ * 4 states: fused into the pre-order pass.  20 / 60 / 61 states (general K-state matrices of discrete-trait models,
+ * dPdp_with_dQdp_general, gensubst.c:284-323): separate kernels on the stored partials -- the first call switches the
+ * engine to phyamd_set_keep_partials(1). */
 int phyamd_parameter_gradient(phyamd_engine *e, int flags, double *lnl, double *cat_gradient, double *parameter_gradient);
 /* Device-resident form for multi-GPU sharding, like phyamd_gradient_device: writes
  * [lnL | g[node][cat] | parameter_gradient[count] | root frequency term[S]]  (1 + (2T-1)*C + count + S doubles, all of them

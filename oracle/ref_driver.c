@@ -16,6 +16,7 @@
  *   ref_driver dump  <spec-file> <out.json>
  *   ref_driver json  <reference-json-file> <out.json>      (run in the dir holding its data files)
  *   ref_driver bench <spec-file> <iters> <warmup>
+ *   ref_driver attr  <attr-spec-file> <out.json>           (one discrete trait per taxon, any state count)
  *
  * spec-file: "key value" lines:
  *   fasta <path>        newick <path-to-file-with-newick>
@@ -26,6 +27,13 @@
  *   categories C        alpha A   (C>1 => discrete gamma)
  *   tipstates 0|1       sse 0|1   rescale 0|1
  *   generic_kernels 0|1 (force the generic-state kernels; needed for 61 states, SURVEY 8a note)
+ *
+ * attr-spec-file (the model src/phycpp/physher.cpp:594-629 assembles: GeneralDataType + AttributePattern +
+ * GeneralSubstitutionModel): "key value" lines:
+ *   states s0,s1,...          ambiguity NAME=s0|s3   (repeatable)
+ *   traits <path>             lines "taxon value", tip id == line index
+ *   newick <path>             structure i,j,...  (rate index of each upper-, then each lower-triangle entry)
+ *   rates r0,r1,...           freqs f0,...       normalize 0|1     categories C   alpha A
  */
 #include <math.h>
 #include <stdarg.h>
@@ -36,6 +44,7 @@
 #include <time.h>
 
 #include "phyc/datatype.h"
+#include "phyc/discreteparameter.h"
 #include "phyc/filereader.h"
 #include "phyc/hashtable.h"
 #include "phyc/mjson.h"
@@ -249,6 +258,103 @@ static built_t build_from_spec(const spec_t *sp) {
 	return b;
 }
 
+/* The assembly of src/phycpp/physher.cpp:53-75 (data type), :321-350 (substitution model), :459-497 (site model)
+ * and :594-629 (attribute pattern + likelihood), driven from an attr-spec file. */
+static built_t build_from_attr_spec(const char *path) {
+	built_t b;
+	memset(&b, 0, sizeof(b));
+	FILE *f = fopen(path, "r");
+	if (!f) { fprintf(stderr, "cannot open spec %s\n", path); exit(2); }
+	char key[64], val[8192], traits[1024] = "", newick_path[1024] = "";
+	char *states[256];
+	int nstates = 0, ncat = 1, normalize = 1, nrates = 0, nfreqs = 0, nstruct = 0;
+	double alpha = 0.5, rates[512], freqs[256], structure_d[4096];
+	char *amb[64];
+	int namb = 0;
+	while (fscanf(f, "%63s %8191s", key, val) == 2) {
+		if (!strcmp(key, "states")) {
+			char *save;
+			for (char *tok = strtok_r(val, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) states[nstates++] = strdup(tok);
+		} else if (!strcmp(key, "ambiguity")) amb[namb++] = strdup(val);
+		else if (!strcmp(key, "traits")) strcpy(traits, val);
+		else if (!strcmp(key, "newick")) strcpy(newick_path, val);
+		else if (!strcmp(key, "structure")) nstruct = parse_list(val, structure_d, 4096);
+		else if (!strcmp(key, "rates")) nrates = parse_list(val, rates, 512);
+		else if (!strcmp(key, "freqs")) nfreqs = parse_list(val, freqs, 256);
+		else if (!strcmp(key, "normalize")) normalize = atoi(val);
+		else if (!strcmp(key, "categories")) ncat = atoi(val);
+		else if (!strcmp(key, "alpha")) alpha = atof(val);
+		else { fprintf(stderr, "unknown attr-spec key %s\n", key); exit(2); }
+	}
+	fclose(f);
+	/* structure: S(S-1) entries = upper triangle then lower triangle, both row by row (gensubst.c:60-79).  The packed
+	 * S(S-1)/2 form selects _reversible_update_Q, which indexes it as a full matrix (gensubst.c:130-151: out of bounds). */
+	if (nfreqs != nstates || nstruct != nstates * (nstates - 1)) { fprintf(stderr, "attr spec: freqs/structure do not match the state count\n"); exit(2); }
+
+	DataType *dt = new_GenericDataType("general_datatype", nstates, (const char **)states);
+	for (int a = 0; a < namb; a++) {
+		char *eq = strchr(amb[a], '=');
+		*eq = 0;
+		const char *members[256];
+		int nm = 0;
+		char *save;
+		for (char *tok = strtok_r(eq + 1, "|", &save); tok; tok = strtok_r(NULL, "|", &save)) members[nm++] = tok;
+		GenericDataType_add_ambiguity(dt, amb[a], nm, members);
+	}
+
+	char *taxa[4096], *values[4096];
+	int ntaxa = 0;
+	f = fopen(traits, "r");
+	if (!f) { fprintf(stderr, "cannot open %s\n", traits); exit(2); }
+	char a1[512], a2[512];
+	while (fscanf(f, "%511s %511s", a1, a2) == 2) {
+		taxa[ntaxa] = strdup(a1);
+		values[ntaxa++] = strdup(a2);
+	}
+	fclose(f);
+	b.patterns = new_AttributePattern(dt, (const char **)taxa, (const char **)values, ntaxa);
+
+	char *newick = slurp(newick_path);
+	b.mtree = new_TreeModel_from_newick(newick, taxa, NULL);
+	free(newick);
+
+	Parameters *rp = new_Parameters(nrates);
+	for (int i = 0; i < nrates; i++) Parameters_move(rp, new_Parameter("subst_rates", rates[i], new_Constraint(0, INFINITY)));
+	Simplex *fs = new_Simplex_with_values("subst_frequency_simplex", freqs, nfreqs);
+	Model *mfs = new_SimplexModel("subst_frequencies", fs);
+	unsigned structure[4096];
+	for (int i = 0; i < nstruct; i++) structure[i] = (unsigned)structure_d[i];
+	DiscreteParameter *dp = new_DiscreteParameter_with_values(structure, nstruct);
+	Model *mdp = new_DiscreteParameterModel("structure", dp);
+	SubstitutionModel *m = new_GeneralModel_with_parameters(dt, (DiscreteParameter *)mdp->obj, rp, fs, -1, normalize);
+	Model *mm = new_SubstitutionModel3("substmodel", m, mfs, NULL, mdp);
+	free_Parameters(rp);
+	mfs->free(mfs);
+
+	b.hash = new_Hashtable_string(10);
+	hashtable_set_key_ownership(b.hash, false);
+	hashtable_set_value_ownership(b.hash, false);
+	char sjs[1024];
+	if (ncat > 1)
+		snprintf(sjs, sizeof sjs,
+		         "{\"id\":\"sitemodel\",\"type\":\"sitemodel\",\"distribution\":{\"distribution\":\"gamma\",\"categories\":%d,\"parameters\":{\"alpha\":{\"id\":\"alpha\",\"type\":\"parameter\",\"value\":%.17g,\"lower\":0,\"upper\":\"infinity\"}}}}",
+		         ncat, alpha);
+	else
+		snprintf(sjs, sizeof sjs, "{\"id\":\"sitemodel\",\"type\":\"sitemodel\"}");
+	b.json = create_json_tree(sjs);
+	Model *msm = new_SiteModel_from_json(b.json, b.hash);
+	SingleTreeLikelihood *tlk = new_SingleTreeLikelihood((Tree *)b.mtree->obj, m, (SiteModel *)msm->obj, b.patterns, NULL, false);
+	b.mlike = new_TreeLikelihoodModel("treelike", tlk, b.mtree, mm, msm, NULL);
+	tlk->include_jacobian = false; /* physher.cpp:627: the C constructor leaves it unset */
+	/* the scalar generic-state kernels: the SSE "even" variants are not valid for odd state counts (treelikelihood.c:1150-1152) */
+	SingleTreeLikelihood_enable_SSE(tlk, false);
+	tlk->update_partials = update_partials_general;
+	tlk->integrate_partials = integrate_partials_general;
+	tlk->node_log_likelihoods = node_log_likelihoods_general;
+	tlk->calculate_per_cat_partials = calculate_branch_partials;
+	return b;
+}
+
 static void jnum(FILE *o, double v);
 
 static void jarr(FILE *o, const char *key, const double *v, size_t n, bool comma) {
@@ -418,6 +524,16 @@ int main(int argc, char **argv) {
 		dump_common(o, b.mlike);
 		dump_gradients_unrooted(o, b.mlike);
 		fprintf(o, "\"source\":\"physher reference (libphyc no-GSL build) via oracle/ref_driver.c\"\n}\n");
+		fclose(o);
+		return 0;
+	}
+	if (!strcmp(argv[1], "attr")) {
+		built_t b = build_from_attr_spec(argv[2]);
+		FILE *o = fopen(argv[3], "w");
+		fprintf(o, "{\n");
+		dump_common(o, b.mlike);
+		dump_gradients_unrooted(o, b.mlike);
+		fprintf(o, "\"source\":\"physher reference via oracle/ref_driver.c attr mode\"\n}\n");
 		fclose(o);
 		return 0;
 	}

@@ -28,8 +28,8 @@ GeneralDataTypeInterface::GeneralDataTypeInterface(const std::vector<std::string
 	dataType_->state_count = (int)states.size();
 	dataType_->symbol_length = (int)states[0].size();
 	dataType_->states = states;
-	// named ambiguity sets (datatype.c:243-262); exact on the 4-state engine (tip masks), "unknown" on the MFMA engines,
-	// whose tips are one state or all states
+	// named ambiguity sets (datatype.c:243-262): exact whenever tip partials are used (4 states: tip masks; 20 / 60 / 61:
+	// the engine's set codes); with tip states they read as "unknown", as every code >= the state count does in the reference
 	if (ambiguities.has_value())
 		for (const auto &kv : *ambiguities) {
 			std::vector<int> set;
@@ -483,26 +483,23 @@ void TreeLikelihoodInterface::Init(bool use_tip_states) {
 	// tlk->mapping: node -> sequence by NAME (treelikelihood.c:1095-1104)
 	std::vector<double> partial((size_t)P * Sp, 0.0), one(S);
 	std::vector<uint8_t> codes_p(P);
-	const bool general_sets = dt.kind == phyamd::DataTypeKind::General && (!dt.ambiguities.empty() || Sp != S);
 	for (int tip = 0; tip < t.tip_count; tip++) {
 		auto it = std::find(names.begin(), names.end(), t.name[tip]);
 		if (it == names.end()) throw Error("Could not find taxon `" + t.name[tip] + "` in alignment");
 		const uint8_t *codes = &impl_->patterns.states[(size_t)(it - names.begin()) * P];
-		if (Sp == 4 && (!use_tip_states || general_sets)) {
-			// "tipstates": false -- datatype->partial per pattern (treelikelihood.c:1106-1117); also how ambiguity sets and
-			// padded state spaces reach the 4-state engine (a 0/1 vector becomes the tip's 4-bit mask; padding states stay 0)
+		if (!use_tip_states) {
+			// "tipstates": false -- datatype->partial per pattern (treelikelihood.c:1106-1117): ambiguity codes and named sets are
+			// exact; states added by padding stay 0 (on the 4-state engine the 0/1 vector becomes the tip's 4-bit mask)
 			for (int k = 0; k < P; k++) {
 				dt.partial(codes[k], one.data());
 				for (int i = 0; i < Sp; i++) partial[(size_t)k * Sp + i] = i < S ? one[i] : 0.0;
 			}
 			phyamd::check(phyamd_set_tip_partials(impl_->engine, tip, partial.data()));
-		} else if (use_tip_states || Sp != S || dt.kind == phyamd::DataTypeKind::General) {
-			// codes >= S (unknown, ambiguity sets of wide general types) become "all states" (sitepattern.h:68-82)
+		} else {
+			// tip states: every code >= S (unknown, ambiguity codes, named sets) reads as "all states" in the reference's
+			// kernels too (sitepattern.h:68-82)
 			for (int k = 0; k < P; k++) codes_p[k] = codes[k] >= S ? (uint8_t)Sp : codes[k];
 			phyamd::check(phyamd_set_tip_states(impl_->engine, tip, codes_p.data()));
-		} else {
-			for (int k = 0; k < P; k++) dt.partial(codes[k], &partial[(size_t)k * S]);
-			phyamd::check(phyamd_set_tip_partials(impl_->engine, tip, partial.data()));
 		}
 	}
 	parameterCount_ = 0;
@@ -521,7 +518,7 @@ void TreeLikelihoodInterface::RequestGradient(std::vector<TreeLikelihoodGradient
 	const phyamd::SiteModel &smc = *siteModel_->GetModel();
 	const bool site_params = smc.dist != phyamd::RateDistribution::Constant || smc.has_pinv || smc.has_mu;
 	const phyamd::SubstModel &mc = *substitutionModel_->GetModel();
-	const bool subst_params = mc.S == 4 && impl_->Sp == 4 && mc.name != "JC69";  // m->dPdp != NULL (gtr.c:102, hky.c:72, gensubst.c:189); device side: 4 states
+	const bool subst_params = mc.name != "JC69";  // m->dPdp != NULL (gtr.c:102, hky.c:72, gensubst.c:189)
 	if (f == 0) {  // TreeLikelihood_initialize_gradient(flags = 0): everything differentiable (treelikelihood.c:255-270)
 		f = (int)TreeLikelihoodGradientFlags::TREE_HEIGHT;
 		if (site_params) f |= (int)TreeLikelihoodGradientFlags::SITE_MODEL;
@@ -531,8 +528,7 @@ void TreeLikelihoodInterface::RequestGradient(std::vector<TreeLikelihoodGradient
 	const int subst_flags = (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL | (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL_RATES |
 	                        (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL_FREQUENCIES;
 	if ((f & subst_flags) && !subst_params)
-		throw Error(mc.S != 4 ? "substitution-model gradients are built for 4-state models only"
-		                      : "this substitution model has no differentiable parameters (no dPdp in the reference either)");
+		throw Error("this substitution model has no differentiable parameters (no dPdp in the reference either)");
 	flags_ = f;
 	// treelikelihood.c:247-249: SUBSTITUTION_MODEL = rates + frequencies
 	substRates_ = f & ((int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL | (int)TreeLikelihoodGradientFlags::SUBSTITUTION_MODEL_RATES);
@@ -643,7 +639,15 @@ void TreeLikelihoodInterface::Gradient(double *gradient) {
 		if (I.dq_v != substitutionModel_->version_ || I.dq_rates != substRates_ || I.dq_freqs != substFreqs_) {
 			std::vector<double> dQ;
 			m.rate_matrix_derivatives(substRates_, substFreqs_, dQ);
-			phyamd::check(phyamd_set_rate_matrix_derivatives(I.engine, (int)(dQ.size() / ((size_t)m.S * m.S)), dQ.data()));
+			const int S = I.S, Sp = I.Sp, count = (int)(dQ.size() / ((size_t)S * S));
+			if (Sp != S) {  // padding states: rows and columns of zeros
+				std::vector<double> padded((size_t)count * Sp * Sp, 0.0);
+				for (int th = 0; th < count; th++)
+					for (int i = 0; i < S; i++)
+						for (int j = 0; j < S; j++) padded[((size_t)th * Sp + i) * Sp + j] = dQ[((size_t)th * S + i) * S + j];
+				dQ.swap(padded);
+			}
+			phyamd::check(phyamd_set_rate_matrix_derivatives(I.engine, count, dQ.data()));
 			I.dq_v = substitutionModel_->version_;
 			I.dq_rates = substRates_;
 			I.dq_freqs = substFreqs_;
@@ -651,7 +655,7 @@ void TreeLikelihoodInterface::Gradient(double *gradient) {
 		subst_grad.resize((substRates_ ? m.rate_parameter_count() : 0) + (substFreqs_ ? m.S : 0));
 		phyamd::check(phyamd_parameter_gradient(I.engine, eflags, &lnl, I.cat_grad.data(), subst_grad.data()));
 		if (substFreqs_) {  // + the root term d lnL / d pi_f (treelikelihood.c:2370-2401)
-			std::vector<double> rootf(m.S);
+			std::vector<double> rootf(I.Sp);  // one entry per engine state; padding states come last
 			phyamd::check(phyamd_root_frequency_term(I.engine, rootf.data()));
 			for (int f = 0; f < m.S; f++) subst_grad[subst_grad.size() - m.S + f] += rootf[f];
 		}

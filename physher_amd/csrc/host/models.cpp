@@ -30,18 +30,25 @@ void build_symmetric_rates(const SubstModel &m, std::vector<double> &R) {
 				set(i, j, idx < (int)m.rates.size() ? m.rates[idx] : 1.0);
 				idx++;
 			}
-	} else if (m.name == "GENERAL") {  // gensubst.c:130-175: structure maps each pair to a rate index
+	} else if (m.name == "GENERAL") {
+		// structure maps each pair of states to a rate index.  Layouts: S(S-1)/2 = the upper triangle row by row (the packed
+		// form of gensubst.c:177-183; the reference's reader of it, :130-151, indexes past the array); S(S-1) = upper then
+		// lower triangle, both row by row (_nonreversible_update_Q, gensubst.c:60-79); S*S = full matrix.
 		const size_t full = (size_t)S * S, tri = (size_t)S * (S - 1) / 2;
-		if (m.structure.size() != full && m.structure.size() != tri) throw Error("GENERAL: structure must have S*S or S*(S-1)/2 entries");
+		const size_t n = m.structure.size();
+		if (n != full && n != tri && !(n == 2 * tri && S > 1)) throw Error("GENERAL: structure must have S*(S-1)/2, S*(S-1) or S*S entries");
 		size_t t = 0;
 		for (int i = 0; i < S; i++)
-			for (int j = i + 1; j < S; j++) {
-				unsigned a;
-				if (m.structure.size() == full) {
+			for (int j = i + 1; j < S; j++, t++) {
+				unsigned a, mirrored;
+				if (n == full) {
 					a = m.structure[(size_t)i * S + j];
-					if (a != m.structure[(size_t)j * S + i]) throw Error("GENERAL: only reversible (symmetric) structures run on this path");
-				} else
-					a = m.structure[t++];
+					mirrored = m.structure[(size_t)j * S + i];
+				} else {
+					a = m.structure[t];
+					mirrored = n == tri ? a : m.structure[tri + (size_t)j * (j - 1) / 2 + i];  // row j of the lower triangle starts at j(j-1)/2
+				}
+				if (a != mirrored) throw Error("GENERAL: only reversible (symmetric) structures run on this path");
 				if (a >= m.rates.size()) throw Error("GENERAL: structure refers to a missing rate");
 				set(i, j, m.rates[a]);
 			}

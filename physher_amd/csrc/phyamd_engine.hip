@@ -171,6 +171,10 @@ struct phyamd_engine {
 
 	// device memory
 	uint8_t *d_tipmask = nullptr;
+	// 20 / 60 / 61 states: tip code S + 1 + q = ambiguity set q, one bit per member state (tip partials that are neither
+	// one state nor all states: named sets of a general data type, states of a padded state space)
+	unsigned long long *d_tipsets = nullptr;
+	std::vector<unsigned long long> tipsets_host;
 	double *d_lower = nullptr, *d_upper = nullptr, *d_mats = nullptr, *d_dmats = nullptr;
 	double *d_Q = nullptr;
 	double *d_Qpi = nullptr;          // diag(pi) Q: the tree-walk gradient contracts u with (pi o Q b) in one mat-vec (4 states)
@@ -195,6 +199,10 @@ struct phyamd_engine {
 	double *d_gen_scratch = nullptr; // rescaled S != 4 path: per-level maxima / numerators / denominators
 	size_t gen_scratch_alloc = 0;
 	size_t np_alloc = 0, np_alloc_B = 0, ppart_alloc = 0;
+	// 20 / 60 / 61 states (k_param_*_gen): branch nodes, node -> stored lower index, per-branch site likelihoods, G tables
+	int *d_pg_nodes = nullptr, *d_pg_core = nullptr;
+	double *d_pg_den = nullptr, *d_pg_Gw = nullptr, *d_pg_B = nullptr;
+	size_t pg_np_alloc = 0;
 	bool params_dirty = true;
 	double *d_model = nullptr, *d_freqs = nullptr, *d_rates = nullptr, *d_props = nullptr, *d_lengths = nullptr, *d_weights = nullptr;
 	double *d_wl = nullptr;  // [P] w_k / L_k from the root kernel (unscaled evaluations)
@@ -820,10 +828,10 @@ int launch_lower_gen(phyamd_engine *e) {
 		const bool is_root = lv == levels - 1;
 		if (is_root)
 			hipLaunchKernelGGL((k_lower_gen<RT, KT, true, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->act_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
+			                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
 		else
 			hipLaunchKernelGGL((k_lower_gen<RT, KT, false, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->act_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
+			                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
 		if (SCALE)
 			hipLaunchKernelGGL(k_scale_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->act_lower_ops + off, e->P, e->Pp, e->S, e->C, e->d_lower, e->d_gen_scratch,
 			                   e->d_lscale, is_root ? e->d_Lc : (double *)nullptr);
@@ -850,7 +858,7 @@ int launch_upper_gen_v(phyamd_engine *e, bool compat) {
 		dim3 grid(e->nblk, cnt, e->C);
 		if (SCALE) mxu = e->d_gen_scratch + (size_t)cnt * 3 * e->C * e->P;
 		hipLaunchKernelGGL((k_upper_gen<RT, KT, FOLD, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-		                   e->d_tipmask, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk, nd, mxu);
+		                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk, nd, mxu);
 		if (SCALE) {
 			hipLaunchKernelGGL(k_scale_upper_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->d_upper_ops + off, e->P, e->Pp, e->S, e->C, e->d_upper, mxu);
 			const int ppb = GenGeo<RT>::PATTERNS_PER_BLOCK;
@@ -1031,6 +1039,66 @@ int update_parameter_matrices(phyamd_engine *e) {
 	return PHYAMD_OK;
 }
 
+// substitution-parameter sums of the 20 / 60 / 61-state engines on the stored partials of a keep-partials gradient
+// (k_param_den_gen ... k_param_contract_gen); dst: [np] on the device
+int launch_parameters_gen(phyamd_engine *e, double *dst) {
+	const int S = e->S, S2 = S * S, np = e->np, B = e->N - 1;
+	int rc;
+	if (!e->d_pg_nodes) {
+		if ((rc = dev_alloc(e, &e->d_pg_nodes, (size_t)B)) || (rc = dev_alloc(e, &e->d_pg_core, (size_t)e->N)) ||
+		    (rc = dev_alloc(e, &e->d_pg_den, (size_t)B * e->P)) || (rc = dev_alloc(e, &e->d_pg_Gw, ((size_t)B * e->C + 1) * S2)))
+			return rc;
+	}
+	if ((size_t)np > e->pg_np_alloc) {
+		dev_free(e, &e->d_pg_B, e->pg_np_alloc * S2);
+		e->pg_np_alloc = 0;
+		if ((rc = dev_alloc(e, &e->d_pg_B, (size_t)np * S2))) return rc;
+		e->pg_np_alloc = np;
+		e->params_dirty = true;
+	}
+	{  // the schedule may have been rebuilt since the last call: the two index tables are N ints
+		std::vector<int> nodes;
+		for (int n = 0; n < e->N; n++)
+			if (n != e->root) nodes.push_back(n);
+		HIP_TRY(hipMemcpyAsync(e->d_pg_nodes, nodes.data(), sizeof(int) * nodes.size(), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipMemcpyAsync(e->d_pg_core, e->core_index.data(), sizeof(int) * e->N, hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+	}
+	if (e->params_dirty) {  // B_theta = U^-1 dQ_theta U
+		const double *evec = e->model.data() + S, *ivec = e->model.data() + S + S2;
+		std::vector<double> Bm((size_t)np * S2), tmp((size_t)S2);
+		for (int th = 0; th < np; th++) {
+			const double *dQ = e->dQ_host.data() + (size_t)th * S2;
+			for (int a = 0; a < S; a++)
+				for (int j = 0; j < S; j++) {
+					double v = 0.0;
+					for (int i = 0; i < S; i++) v += ivec[a * S + i] * dQ[i * S + j];
+					tmp[a * S + j] = v;
+				}
+			for (int a = 0; a < S; a++)
+				for (int b = 0; b < S; b++) {
+					double v = 0.0;
+					for (int j = 0; j < S; j++) v += tmp[a * S + j] * evec[j * S + b];
+					Bm[((size_t)th * S + a) * S + b] = v;
+				}
+		}
+		HIP_TRY(hipMemcpyAsync(e->d_pg_B, Bm.data(), sizeof(double) * Bm.size(), hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		e->params_dirty = false;
+	}
+	hipLaunchKernelGGL(k_param_den_gen, dim3((e->P + 255) / 256, B), dim3(256), 0, e->stream, e->d_pg_nodes, e->T, e->P, e->Pp, S, e->C, e->d_pg_core, e->d_tipmask,
+	                   e->d_tipsets, e->d_lower, e->d_upper, e->d_mats, e->d_freqs, e->d_props, e->d_pg_den);
+	const size_t lds = sizeof(double) * 2 * (size_t)std::max(S2, S * (PARAM_CHUNK + 1));
+	hipLaunchKernelGGL(k_param_outer_gen, dim3(B, e->C), dim3(256), lds, e->stream, e->d_pg_nodes, e->T, e->P, e->Pp, S, e->C, e->d_pg_core, e->d_tipmask,
+	                   e->d_tipsets, e->d_lower, e->d_upper, e->d_model, e->d_freqs, e->d_props, e->d_rates, e->d_lengths, e->d_explicit, e->d_weights,
+	                   e->d_pg_den, e->d_pg_Gw);
+	double *Gsum = e->d_pg_Gw + (size_t)B * e->C * S2;
+	hipLaunchKernelGGL(k_param_sum_gen, dim3((S2 + 255) / 256), dim3(256), 0, e->stream, B * e->C, S2, e->d_pg_Gw, Gsum);
+	hipLaunchKernelGGL(k_param_contract_gen, dim3(np), dim3(64), 0, e->stream, S2, e->d_pg_B, Gsum, dst);
+	HIP_TRY(hipGetLastError());
+	return PHYAMD_OK;
+}
+
 // d lnL / d pi_f through the root frequencies, f < S, written to dst (device) on the engine's stream
 int launch_root_frequency_term(phyamd_engine *e, double *dst) {
 	int rc;
@@ -1050,11 +1118,16 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 	int rc;
 	e->upper_fold = (flags & PHYAMD_GRAD_FOLD_ROOT_FREQS) != 0;
 	if (with_params) {
-		if (e->generic) return fail(PHYAMD_EUNSUPPORTED, "substitution-parameter gradients are built for 4-state models only");
 		if (e->np < 1) return fail(PHYAMD_EINVAL, "phyamd_set_rate_matrix_derivatives has not been called");
 		if (!e->have_eigen) return fail(PHYAMD_EINVAL, "substitution-parameter gradients need the eigen system (phyamd_set_eigen)");
 		if (flags & PHYAMD_GRAD_FOLD_ROOT_FREQS)
 			return fail(PHYAMD_EINVAL, "PHYAMD_GRAD_FOLD_ROOT_FREQS cannot be combined with parameter gradients (the reference clears include_root_freqs, treelikelihood.c:291-305)");
+	}
+	if (with_params && e->generic && !e->keep_partials) {
+		// the 20 / 60 / 61-state parameter kernels read every node's lower and upper partial: keep them from here on
+		if ((rc = bind_device(e))) return rc;
+		e->keep_partials = true;
+		if ((rc = rebuild_schedule(e))) return rc;
 	}
 	if ((rc = run_lower(e, true))) return rc;
 	if ((flags & PHYAMD_GRAD_FOLD_ROOT_FREQS) && e->scaling_on && e->fused) {
@@ -1065,13 +1138,13 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 		if ((rc = rebuild_schedule(e))) return rc;
 		if ((rc = run_lower(e, true))) return rc;
 	}
-	if (with_params && !(e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on)))
+	if (with_params && !e->generic && !(e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on)))
 		e->level_upper_needed = true;
 	if ((rc = ensure_upper_storage(e))) return rc;
 	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
 	e->grad_blocks = e->nblk;
 	// (the compat flag changes only the branch terms; parameter sums always use the mixture denominator: level kernels then)
-	const bool walk_params = with_params && e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on);
+	const bool walk_params = with_params && !e->generic && e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on);
 	if (walk_params) {
 		const int waves = e->C * e->G;
 		if (e->scaling_on)
@@ -1079,7 +1152,7 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 		else
 			rc = waves <= 4 ? launch_upper_walk_params<4, false>(e) : waves <= 8 ? launch_upper_walk_params<8, false>(e) : launch_upper_walk_params<16, false>(e);
 		if (rc) return rc;
-	} else if (with_params) {
+	} else if (with_params && !e->generic) {
 		if ((rc = update_parameter_matrices(e))) return rc;
 		if ((rc = launch_upper_params(e, flags))) return rc;
 	} else if ((rc = launch_upper(e, flags)))
@@ -1087,6 +1160,9 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 	record(e, 3);
 	hipLaunchKernelGGL(k_reduce_rows, dim3(e->N * e->C), dim3(64), 0, e->stream, e->d_gpart, e->grad_blocks, e->d_row_valid, e->d_result + 1);
 	if (walk_params) {
+		if ((rc = launch_root_frequency_term(e, e->d_result + 1 + (size_t)e->N * e->C + e->np))) return rc;
+	} else if (with_params && e->generic) {
+		if ((rc = launch_parameters_gen(e, e->d_result + 1 + (size_t)e->N * e->C))) return rc;
 		if ((rc = launch_root_frequency_term(e, e->d_result + 1 + (size_t)e->N * e->C + e->np))) return rc;
 	} else if (with_params) {  // [np][ops][nblk] -> [np][ops] -> [np], fixed order
 		const int ops = (int)e->upper_ops.size();
@@ -1213,6 +1289,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	}
 	int rc;
 	if ((rc = dev_alloc(e, &e->d_tipmask, (size_t)e->T * e->P))) return bail(rc);
+	if (e->generic && (rc = dev_alloc(e, &e->d_tipsets, (size_t)256))) return bail(rc);
 	// d_lower is sized by the schedule (stored "core" nodes only): ensure_lower_storage
 	if ((rc = dev_alloc(e, &e->d_mats, msz))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_dmats, msz))) return bail(rc);
@@ -1253,7 +1330,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_tipsets, (void *)e->d_pg_nodes, (void *)e->d_pg_core, (void *)e->d_pg_den, (void *)e->d_pg_Gw, (void *)e->d_pg_B, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops, (void *)e->d_Qpi})
@@ -1291,19 +1368,31 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	std::vector<uint8_t> mask(e->P);
-	if (e->generic) {  // one-hot or all-ones vectors only (what datatype.c:212-240 produces without ambiguity tables)
+	if (e->generic) {  // 0/1 vectors: one state, all states, or a set of states (datatype.c:212-240)
 		const int S = e->S;
+		bool grew = false;
 		for (int k = 0; k < e->P; k++) {
 			int ones = 0, last = -1;
+			unsigned long long members = 0;
 			for (int s = 0; s < S; s++) {
 				const double v = partials[(size_t)k * S + s];
-				if (v == 1.0) ones++, last = s;
+				if (v == 1.0) ones++, last = s, members |= 1ull << s;
 				else if (v != 0.0) return fail(PHYAMD_EUNSUPPORTED, "tip %d pattern %d: only 0/1 tip partials are built", tip, k);
 			}
 			if (ones == 1) mask[k] = (uint8_t)last;
 			else if (ones == S) mask[k] = (uint8_t)S;
-			else return fail(PHYAMD_EUNSUPPORTED, "tip %d pattern %d: partial ambiguity sets are only built for 4 states", tip, k);
+			else {
+				size_t q = std::find(e->tipsets_host.begin(), e->tipsets_host.end(), members) - e->tipsets_host.begin();
+				if (q == e->tipsets_host.size()) {
+					if ((int)q + S + 1 > 255) return fail(PHYAMD_EUNSUPPORTED, "tip %d pattern %d: more than %d distinct ambiguity sets", tip, k, 255 - S);
+					e->tipsets_host.push_back(members);
+					grew = true;
+				}
+				mask[k] = (uint8_t)(S + 1 + q);
+			}
 		}
+		if (grew)
+			HIP_TRY(hipMemcpyAsync(e->d_tipsets, e->tipsets_host.data(), e->tipsets_host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, e->stream));
 		HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
 		HIP_TRY(hipStreamSynchronize(e->stream));
 		e->tip_set[tip] = 1;
@@ -1556,7 +1645,6 @@ int phyamd_set_rate_matrix_derivatives(phyamd_engine *e, int count, const double
 	CHECK_ENGINE(e);
 	if (count < 0 || count > PHYAMD_MAX_PARAMETERS) return fail(PHYAMD_EINVAL, "count %d outside 0..%d", count, PHYAMD_MAX_PARAMETERS);
 	if (count > 0 && !dQ) return fail(PHYAMD_EINVAL, "null dQ");
-	if (count > 0 && e->generic) return fail(PHYAMD_EUNSUPPORTED, "substitution-parameter gradients are built for 4-state models only");
 	e->np = count;
 	e->dQ_host.assign(dQ, dQ + (size_t)count * e->S * e->S);
 	e->params_dirty = true;
@@ -1711,7 +1799,9 @@ int phyamd_get_partials(phyamd_engine *e, int node, int upper, double *out) {
 		for (int c = 0; c < e->C; c++)
 			for (int k = 0; k < e->P; k++)
 				for (int s = 0; s < S; s++)
-					out[((size_t)c * e->P + k) * S + s] = e->generic ? ((mask[k] >= S || mask[k] == s) ? 1.0 : 0.0) : ((mask[k] >> s) & 1 ? 1.0 : 0.0);
+					out[((size_t)c * e->P + k) * S + s] = !e->generic        ? ((mask[k] >> s) & 1 ? 1.0 : 0.0)
+					                                      : mask[k] > S      ? (double)((e->tipsets_host[mask[k] - S - 1] >> s) & 1)
+					                                      : (mask[k] == S || mask[k] == s) ? 1.0 : 0.0;
 		return PHYAMD_OK;
 	}
 	if (!upper && e->core_index[node] < 0)

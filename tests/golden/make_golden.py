@@ -7,7 +7,7 @@ Inputs are seeded synthetic alignments/trees from physher_amd/synth.py, plus the
 test data files (tests/data/fluA.fa + jc69-time.json: data fixtures of its known-answer test).
 
 Each case directory holds: aln.fa, tree.nwk, spec.txt (inputs) and expected.json.gz (outputs of the
-reference).  Re-running this script must reproduce the committed files byte for byte.
+reference); the discrete-trait cases hold traits.txt, tree.nwk, trait_spec.txt instead.  Re-running this script must reproduce the committed files byte for byte.
 """
 import gzip
 import json
@@ -165,6 +165,83 @@ def run_fluA_hky_g4():
     print(f"fluA_hky_g4_time: lnL={data['lnl_jacobian0']!r}, gradient blocks={len(data['gradient_all_time'])} flags={data['gradient_all_time_flags']}")
 
 
+ATTR_CASES = [
+    # discrete traits (one attribute per taxon, general data type): the wrapper's second constructor (physher.cpp:594-629)
+    ("trait_k5_g3_t14", dict(T=14, K=5, seed=21, categories=3, alpha=0.8, n_rates=3, unknown=(3,), ambiguities={})),
+    ("trait_k7_sets_t12", dict(T=12, K=7, seed=22, categories=1, n_rates=21, unknown=(5,),
+                               ambiguities={"north": (0, 1, 2), "coast": (2, 5)}, ambiguous_tips={1: "north", 8: "coast"})),
+    ("trait_k2_t9", dict(T=9, K=2, seed=23, categories=1, n_rates=1, unknown=(), ambiguities={})),
+]
+
+
+def reference_consistent_structure(K, n_rates):
+    """A symmetric rate-class assignment in the only layout the reference's general model reads consistently.
+
+    new_GeneralModel_with_parameters (gensubst.c:177-200) takes the S(S-1)/2 packed form to _reversible_update_Q, which
+    indexes it as a full matrix (gensubst.c:130-151: out-of-bounds reads).  The S(S-1) form goes through
+    _nonreversible_update_Q (upper triangle row by row, then lower triangle row by row, gensubst.c:60-79), but _general_dQdp
+    (gensubst.c:227-260) walks the lower triangle in the order of the mirrored upper one.  The two orders agree when pairs
+    sharing a position share a rate class: merge those pairs, then deal classes out to the rates."""
+    lower_rows = [(i, j) for i in range(1, K) for j in range(i)]
+    lower_mirrored = [(j, i) for i in range(K) for j in range(i + 1, K)]
+    parent = {p: p for p in lower_rows}
+
+    def find(x):
+        while parent[x] != x:
+            x = parent[x]
+        return x
+    for a, b in zip(lower_rows, lower_mirrored):
+        parent[find(a)] = find(b)
+    roots = sorted({find(p) for p in lower_rows})
+    cls = {p: roots.index(find(p)) % n_rates for p in lower_rows}
+    upper = [cls[(j, i)] for i in range(K) for j in range(i + 1, K)]
+    lower = [cls[p] for p in lower_rows]
+    assert lower == [cls[p] for p in lower_mirrored]
+    return upper + lower, len(roots)
+
+
+def run_attr_case(name, o):
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(o["seed"])
+    T, K = o["T"], o["K"]
+    tree = synth.random_tree(T, rng, bl_low=0.05, bl_high=0.6)
+    states = [f"loc{i}" for i in range(K)]
+    values = [states[c] for c in rng.integers(0, K, size=T)]
+    for i in o["unknown"]:
+        values[i] = "?"
+    for i, a in o.get("ambiguous_tips", {}).items():
+        values[i] = a
+    with open(os.path.join(d, "traits.txt"), "w") as f:
+        f.write("".join(f"{n} {v}\n" for n, v in zip(tree.names, values)))
+    with open(os.path.join(d, "tree.nwk"), "w") as f:
+        f.write(tree.newick() + "\n")
+    structure, n_classes = reference_consistent_structure(K, o["n_rates"])
+    rates = np.round(rng.uniform(0.3, 2.5, size=o["n_rates"]), 3)
+    freqs = rng.dirichlet(np.full(K, 4.0))
+    spec = ["states " + ",".join(states)]
+    spec += [f"ambiguity {a}=" + "|".join(states[i] for i in m) for a, m in o["ambiguities"].items()]
+    spec += [f"traits {d}/traits.txt", f"newick {d}/tree.nwk", "structure " + ",".join(map(str, structure)),
+             "rates " + ",".join(repr(float(x)) for x in rates), "freqs " + ",".join(repr(float(x)) for x in freqs),
+             "normalize 1", f"categories {o['categories']}"]
+    if "alpha" in o:
+        spec.append(f"alpha {o['alpha']}")
+    tmp_spec = os.path.join(d, "spec.abs.txt")
+    with open(tmp_spec, "w") as f:
+        f.write("\n".join(spec) + "\n")
+    with open(os.path.join(d, "trait_spec.txt"), "w") as f:
+        f.write("\n".join(s.replace(d + "/", "") for s in spec) + "\n")
+    out = os.path.join(d, "expected.json")
+    subprocess.check_call([DRIVER, "attr", tmp_spec, out], stdout=subprocess.DEVNULL)
+    os.remove(tmp_spec)
+    with open(out) as f:
+        data = json.load(f)
+    os.remove(out)
+    with gzip.GzipFile(out + ".gz", "w", mtime=0) as f:
+        f.write(json.dumps(data, separators=(",", ":")).encode())
+    print(f"{name}: K={data['state_count']} lnL={data['lnl']!r} gradient_all={len(data['gradient_all'])} flags={data['gradient_all_flags']}")
+
+
 if __name__ == "__main__":
     build_ref()
     only = sys.argv[1:]
@@ -175,3 +252,6 @@ if __name__ == "__main__":
         run_fluA()
     if not only or "fluA_hky_g4_time" in only:
         run_fluA_hky_g4()
+    for name, opts in ATTR_CASES:
+        if not only or name in only:
+            run_attr_case(name, opts)

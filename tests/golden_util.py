@@ -11,6 +11,41 @@ UNROOTED_CASES = sorted(
     d for d in os.listdir(GOLDEN)
     if os.path.isfile(os.path.join(GOLDEN, d, "spec.txt")))
 
+# discrete-trait cases (one attribute per taxon, general data type): trait_spec.txt + traits.txt + tree.nwk
+TRAIT_CASES = sorted(
+    d for d in os.listdir(GOLDEN)
+    if os.path.isfile(os.path.join(GOLDEN, d, "trait_spec.txt")))
+
+
+def read_trait_case(case):
+    """Inputs of a discrete-trait case: states, named ambiguity sets (in the order they were added), taxa and their
+    attribute values (tip id == line index), newick, and the general model's structure / rates / frequencies."""
+    d = os.path.join(GOLDEN, case)
+    out = {"ambiguities": {}, "categories": 1, "alpha": 0.5}
+    with open(os.path.join(d, "trait_spec.txt")) as f:
+        for line in f:
+            k, v = line.split()
+            if k == "states":
+                out["states"] = v.split(",")
+            elif k == "ambiguity":
+                name, members = v.split("=")
+                out["ambiguities"][name] = members.split("|")
+            elif k == "structure":
+                out["structure"] = [int(x) for x in v.split(",")]
+            elif k in ("rates", "freqs"):
+                out[k] = [float(x) for x in v.split(",")]
+            elif k in ("categories", "normalize"):
+                out[k] = int(v)
+            elif k == "alpha":
+                out[k] = float(v)
+    with open(os.path.join(d, "traits.txt")) as f:
+        rows = [line.split() for line in f if line.strip()]
+    out["taxa"] = [r[0] for r in rows]
+    out["values"] = [r[1] for r in rows]
+    with open(os.path.join(d, "tree.nwk")) as f:
+        out["newick"] = f.read().strip()
+    return out
+
 
 def read_fasta(path):
     names, seqs = [], []

@@ -408,6 +408,38 @@ def test_generic_states_forced_rescaling(S, T, P, C):
     _compare_with_oracle(pb, RESCALE_ALWAYS, flags=GRAD_FOLD_ROOT_FREQS)
 
 
+@pytest.mark.parametrize("S,T,P,C,rescale", [(20, 14, 150, 2, RESCALE_NEVER), (61, 9, 40, 1, RESCALE_NEVER), (20, 50, 70, 2, RESCALE_ALWAYS)])
+def test_generic_states_ambiguity_sets(S, T, P, C, rescale):
+    """Tip partials that are sets of states (named ambiguities of a general data type, datatype.c:212-262) on the MFMA
+    engines: the tip's message is the sum of the set's columns.  A fifth of the tip cells carry one of a handful of random
+    sets, some are unknown, the rest one state; lnL, all partials and the gradient against the oracle run on the same
+    0/1 tip vectors, and the tip partial reads back as it was given."""
+    forced = rescale == RESCALE_ALWAYS
+    pb = random_problem(T, P, C, seed=900 + S + T, S=S, gaps=0.03, bl=(0.3, 0.9) if forced else (0.01, 0.1), rescale=1 if forced else 0)
+    rng = np.random.default_rng(S * T)
+    sets = [rng.random(S) < rng.uniform(0.1, 0.6) for _ in range(7)]
+    sets = [s for s in sets if 1 < s.sum() < S]
+    tp = np.zeros((T, P, S))
+    for t in range(T):
+        for k in range(P):
+            code = pb.tip_states[t, k]
+            if code >= S:
+                tp[t, k, :] = 1.0
+            elif rng.random() < 0.2:
+                tp[t, k, sets[rng.integers(len(sets))]] = 1.0
+                tp[t, k, code] = 1.0  # keep the observed state inside the set (several distinct sets arise this way)
+            else:
+                tp[t, k, code] = 1.0
+    pb2 = po.Problem(pb.left, pb.right, pb.root, pb.weights, pb.eval, pb.evec, pb.ivec, pb.freqs, pb.cat_rates, pb.cat_props,
+                     pb.branch_lengths, tip_states=pb.tip_states, tip_partials=tp, rescale=1 if forced else 0)
+    _compare_with_oracle(pb2, rescale, tip_mode="partials", check_partials=True)
+    with engine_from_problem(pb2, rescale=rescale, tip_mode="partials") as e:
+        for t in (0, T - 1):
+            got = e.partials(t)
+            for c in range(C):
+                np.testing.assert_array_equal(got[c], tp[t])
+
+
 def test_generic_states_lazy_rescaling_switch():
     pb = random_problem(400, 20, 2, seed=21, S=20, bl=(0.5, 1.5), rescale=2)
     ref = pb.gradient()
@@ -542,10 +574,32 @@ def test_parameter_gradient_argument_checks():
         assert np.all(pg == 0.0)
         with pytest.raises(EngineError):
             e.set_rate_matrix_derivatives(np.zeros((65, 4, 4)))
-    pb20 = random_problem(6, 50, 1, seed=4, S=20)
-    with engine_from_problem(pb20) as e:
-        with pytest.raises(EngineError):
-            e.set_rate_matrix_derivatives(np.zeros((1, 20, 20)))
+
+
+@pytest.mark.parametrize("S,T,P,C,rescale", [(20, 11, 1, 1, 0), (20, 17, 90, 3, 0), (61, 8, 37, 2, 0), (60, 6, 5, 1, 0), (20, 70, 40, 2, 1), (61, 40, 9, 1, 1)])
+def test_parameter_gradient_generic_states(S, T, P, C, rescale):
+    """G2 for 20 / 60 / 61 states (general K-state rate matrices of discrete-trait models, gensubst.c:284-323): the engine
+    keeps every partial and forms the per-branch outer products in the eigen basis; against the oracle, with gaps, unscaled
+    and rescaled, and together with the per-category branch gradient of the same call."""
+    pb = random_problem(T, P, C, seed=S * 100 + T, S=S, gaps=0.05, bl=(0.3, 0.9) if rescale else (0.01, 0.2), rescale=rescale)
+    rng = np.random.default_rng(S + T)
+    dQ = rng.normal(size=(5, S, S))
+    dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(S)[None]
+    _, og = po.parameter_gradient(pb, dQ)
+    orf = po.root_frequency_term(pb)
+    ref = pb.gradient()
+    with engine_from_problem(pb, rescale=RESCALE_ALWAYS if rescale else RESCALE_NEVER) as e:
+        e.set_rate_matrix_derivatives(dQ)
+        lnl, cg, pg = e.parameter_gradient()
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        assert e.rescaling == bool(rescale)
+        assert np.abs(pg - og).max() <= 1e-9 * max(1.0, np.abs(og).max())
+        np.testing.assert_allclose(e.root_frequency_term(), orf, rtol=1e-10)
+        assert np.abs(cg - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+        lnl2, cg2 = e.gradient()  # the plain gradient still runs on the same engine, now in keep-partials mode
+        assert lnl2 == lnl and np.array_equal(cg2, cg)
+        lnl3, _, pg3 = e.parameter_gradient()
+        assert lnl3 == lnl and np.array_equal(pg3, pg)  # fixed-order sums: reproducible
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import GOLDEN, UNROOTED_CASES, load, read_fasta, read_spec
+from golden_util import GOLDEN, TRAIT_CASES, UNROOTED_CASES, load, read_fasta, read_spec, read_trait_case
 
 pytestmark = pytest.mark.gpu
 
@@ -360,6 +360,46 @@ def test_attribute_patterns_with_ambiguity_sets():
                     tip_states=np.zeros((T, 1), dtype=np.uint8), tip_partials=tp)
     ref = pb.log_likelihood()
     assert abs(tlk.log_likelihood() - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+
+
+@pytest.mark.parametrize("tip_states", [False, True])
+@pytest.mark.parametrize("case", TRAIT_CASES)
+def test_discrete_traits_match_reference(case, tip_states):
+    """Discrete-trait fixtures generated from the compiled reference (tests/golden/make_golden.py::run_attr_case): K = 2, 5
+    and 7 states (padded here to the 4- and 20-state kernels), named ambiguity sets and unknowns, with and without gamma
+    categories -- lnL and every gradient block (branches, gamma shape, rates, frequencies) in the reference's order."""
+    from physher_amd import _phycpp_amd as pc
+    F = pc.TreeLikelihoodGradientFlags
+    tc, gold = read_trait_case(case), load(case)
+    K, n_rates = len(tc["states"]), len(tc["rates"])
+    has_sets = bool(tc["ambiguities"])
+    if tip_states and has_sets:
+        pytest.skip("named ambiguity sets need tip partials (the wrapper raises, tested below)")
+    dt = pc.GeneralDataTypeInterface(tc["states"], tc["ambiguities"] or None)
+    subst = pc.GeneralSubstitutionModelInterface(dt, tc["rates"], tc["freqs"], tc["structure"], True)
+    site = pc.GammaSiteModelInterface(tc["alpha"], tc["categories"], None, None) if tc["categories"] > 1 else pc.ConstantSiteModelInterface(None)
+    tree = pc.UnRootedTreeModelInterface(tc["newick"], tc["taxa"])
+    tlk = pc.TreeLikelihoodInterface(tc["taxa"], tc["values"], tree, subst, site, None, use_tip_states=tip_states)
+    assert tlk.get_pattern_count() == 1
+    lnl = tlk.log_likelihood()
+    assert abs(lnl - gold["lnl"]) <= 1e-10 * abs(gold["lnl"])
+    N = gold["node_count"]
+    n_site = 1 if tc["categories"] > 1 else 0
+    ref = gold["gradient_all"]
+    assert len(ref) == N + n_site + n_rates + K
+    flags = [F.TREE_HEIGHT, F.SUBSTITUTION_MODEL] + ([F.SITE_MODEL] if n_site else [])
+    tlk.request_gradient(flags)
+    assert tlk.gradient_length == N - 2 + n_site + n_rates + K
+    g = tlk.gradient()
+    node_map = tree.node_map
+    scale = max(1.0, np.abs(ref[:N]).max())
+    skipped = {gold["root"], int(gold["right"][gold["root"]])}
+    for i in range(N - 2):  # physher.cpp:649-655
+        if i not in skipped:
+            assert abs(g[node_map[i]] - ref[i]) <= 1e-9 * scale, (i, g[node_map[i]], ref[i])
+    if n_site:
+        assert abs(g[N - 2] - ref[N]) <= 2e-7 * max(1.0, abs(ref[N]))  # the reference's own central difference
+    np.testing.assert_allclose(g[N - 2 + n_site:], ref[N + n_site:], rtol=2e-8, atol=1e-7)
 
 
 def test_fluA_time_tree_hky_gamma_all_gradient_blocks():
