@@ -159,7 +159,8 @@ int phyamd_root_frequency_term(phyamd_engine *e, double *out /* [S] */);
  * lnL and its first two derivatives with respect to the length of ONE branch, evaluated at a TRIAL length from the upper
  * and lower partials that meet on the branch -- O(patterns) work per trial instead of a tree sweep.  Needs
  * phyamd_set_keep_partials(1) and a phyamd_gradient call for the current parameters (which leaves every upper partial
- * resident); 4 states, unscaled evaluations.  Any of lnl / d1 / d2 may be NULL.  The engine's branch lengths are not
+ * resident); every state count, rescaled evaluations included (their stored partials are anchored on the per-pattern lnL
+ * they belong to).  Any of lnl / d1 / d2 may be NULL.  The engine's branch lengths are not
  * changed: accept a length with phyamd_set_branch_length and re-evaluate. */
 int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, double *lnl, double *d1, double *d2);
 int phyamd_synchronize(phyamd_engine *e);

@@ -1693,44 +1693,55 @@ int phyamd_root_frequency_term(phyamd_engine *e, double *out) {
 
 int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, double *lnl, double *d1, double *d2) {
 	CHECK_ENGINE(e);
-	if (e->generic) return fail(PHYAMD_EUNSUPPORTED, "the single-branch evaluation is built for 4-state models");
-	if (e->scaling_on) return fail(PHYAMD_EUNSUPPORTED, "the single-branch evaluation is not built for rescaled evaluations (upper scale factors are not kept)");
 	if (node < 0 || node >= e->N || node == e->root) return fail(PHYAMD_EINVAL, "node %d has no branch", node);
 	if (!e->keep_partials || !e->upper_valid)
 		return fail(PHYAMD_EINVAL, "the single-branch evaluation needs the partials of phyamd_gradient with phyamd_set_keep_partials(1)");
 	if (!e->have_eigen) return fail(PHYAMD_EINVAL, "the single-branch evaluation needs the eigen system (phyamd_set_eigen)");
 	int rc;
 	if ((rc = bind_device(e))) return rc;
-	const int C = e->C, nb = (e->P + WAVE - 1) / WAVE;
-	const size_t need = (size_t)C * 48 + (size_t)3 * nb + 3;
+	const int C = e->C, S = e->S, S2 = S * S;
+	const int per_block = e->generic ? 256 : WAVE, nb = (e->P + per_block - 1) / per_block;
+	const size_t msz = (size_t)C * (e->generic ? 4 : 3) * S2, need = msz + (size_t)3 * nb + 3;
 	if (!e->d_branch && (rc = dev_alloc(e, &e->d_branch, need))) return rc;
-	// P(t r_c), r_c Q P, r_c^2 Q Q P from the eigen system (4x4, host)
-	const double *ev = e->model.data(), *U = ev + 4, *Ui = U + 16;
-	std::vector<double> pm((size_t)C * 48);
+	// P(t r_c), r_c Q P, r_c^2 Q Q P from the eigen system (host: S^3 per category)
+	const double *ev = e->model.data(), *U = ev + S, *Ui = U + S2;
+	std::vector<double> pm(msz), ex(S);
+	const int stride = e->generic ? 4 * S2 : 48;
 	for (int c = 0; c < C; c++) {
 		const double r = e->rates[c], t = length * r;
-		for (int i = 0; i < 4; i++)
-			for (int j = 0; j < 4; j++) {
+		for (int a = 0; a < S; a++) ex[a] = std::exp(ev[a] * t);
+		for (int i = 0; i < S; i++)
+			for (int j = 0; j < S; j++) {
 				double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-				for (int a = 0; a < 4; a++) {
-					const double w = U[i * 4 + a] * Ui[a * 4 + j], ex = std::exp(ev[a] * t);
-					p0 += w * ex;
-					p1 += w * ev[a] * ex;
-					p2 += w * ev[a] * ev[a] * ex;
+				for (int a = 0; a < S; a++) {
+					const double w = U[i * S + a] * Ui[a * S + j] * ex[a];
+					p0 += w;
+					p1 += w * ev[a];
+					p2 += w * ev[a] * ev[a];
 				}
-				pm[(size_t)c * 48 + i * 4 + j] = std::fabs(p0);  // substmodel.c:552
-				pm[(size_t)c * 48 + 16 + i * 4 + j] = r * p1;
-				pm[(size_t)c * 48 + 32 + i * 4 + j] = r * r * p2;
+				pm[(size_t)c * stride + i * S + j] = std::fabs(p0);  // substmodel.c:552
+				pm[(size_t)c * stride + S2 + i * S + j] = r * p1;
+				pm[(size_t)c * stride + 2 * S2 + i * S + j] = r * r * p2;
 			}
 	}
 	HIP_TRY(hipMemcpyAsync(e->d_branch, pm.data(), sizeof(double) * pm.size(), hipMemcpyHostToDevice, e->stream));
+	// rescaled evaluations: the per-pattern lnL of the resident evaluation anchors the stored (scaled) partials
+	const double *plk = e->scaling_on ? e->d_plk : nullptr;
+	const double *m0 = e->d_mats + (size_t)node * C * S2;
 	const size_t npd = node_partial_doubles(e);
 	const double *up = e->d_upper + (size_t)e->upper_slot[node] * npd;
 	const double *low = node < e->T ? nullptr : e->d_lower + (size_t)e->core_index[node] * npd;
-	double *part = e->d_branch + (size_t)C * 48;
-	hipLaunchKernelGGL(k_branch_eval4, dim3(nb), dim3(WAVE, C), sizeof(double) * 3 * C * WAVE, e->stream, e->P, C, up, low,
-	                   node < e->T ? e->d_tipmask + (size_t)node * e->P : (const uint8_t *)nullptr, e->d_branch, e->d_freqs, e->upper_fold ? 1 : 0, e->d_props,
-	                   e->d_weights, part);
+	double *part = e->d_branch + msz;
+	if (e->generic) {
+		if (plk)
+			for (int c = 0; c < C; c++)
+				HIP_TRY(hipMemcpyAsync(e->d_branch + (size_t)c * stride + 3 * S2, m0 + (size_t)c * S2, sizeof(double) * S2, hipMemcpyDeviceToDevice, e->stream));
+		hipLaunchKernelGGL(k_branch_eval_gen, dim3(nb), dim3(256), 0, e->stream, node, e->T, e->P, e->Pp, S, C, up, low, e->d_tipmask, e->d_tipsets, e->d_branch,
+		                   e->d_freqs, e->upper_fold ? 1 : 0, e->d_props, e->d_weights, plk, part);
+	} else
+		hipLaunchKernelGGL(k_branch_eval4, dim3(nb), dim3(WAVE, C), sizeof(double) * 4 * C * WAVE, e->stream, e->P, C, up, low,
+		                   node < e->T ? e->d_tipmask + (size_t)node * e->P : (const uint8_t *)nullptr, e->d_branch, e->d_freqs, e->upper_fold ? 1 : 0,
+		                   e->d_props, e->d_weights, plk, m0, part);
 	hipLaunchKernelGGL(k_reduce_rows, dim3(3), dim3(64), 0, e->stream, part, nb, (const uint8_t *)nullptr, part + (size_t)3 * nb);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_result, part + (size_t)3 * nb, sizeof(double) * 3, hipMemcpyDeviceToHost, e->stream));

@@ -654,14 +654,17 @@ def test_single_branch_updates_recompute_only_the_path_to_the_root(S, T, P, C, r
 # ---------------------------------------------------------------------------------------------------------
 # f.2: the optimiser's fast path -- lnL and two derivatives along ONE branch from the resident partials
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("T,P,C,fold", [(20, 333, 4, 0), (9, 64, 1, 0), (14, 100, 3, 1)])
-def test_single_branch_evaluation(T, P, C, fold):
+@pytest.mark.parametrize("S,T,P,C,fold,rescale", [(4, 20, 333, 4, 0, 0), (4, 9, 64, 1, 0, 0), (4, 14, 100, 3, 1, 0), (4, 60, 150, 4, 0, 1), (4, 30, 70, 1, 0, 1),
+                                                  (20, 12, 90, 2, 0, 0), (61, 8, 33, 1, 0, 0), (20, 50, 40, 2, 0, 1), (60, 7, 300, 1, 1, 0)])
+def test_single_branch_evaluation(S, T, P, C, fold, rescale):
     """phyamd_branch_log_likelihood against full recomputations: lnL(t) for trial lengths of tip and internal branches,
     d1 against the branch gradient and central differences, d2 against central differences of d1
-    (_calculate_uppper / dlnldt_uppper / d2lnldt2_uppper, treelikelihood.c:2196-2335, 2592-2686)."""
-    pb = random_problem(T, P, C, seed=60 + T, gaps=0.03, fold_root_freqs=fold)
+    (_calculate_uppper / dlnldt_uppper / d2lnldt2_uppper, treelikelihood.c:2196-2335, 2592-2686).  Every state count;
+    rescaled evaluations anchor the stored (scaled) partials on the per-pattern lnL they belong to."""
+    pb = random_problem(T, P, C, seed=60 + T + S, S=S, gaps=0.03, fold_root_freqs=fold, bl=(0.3, 0.9) if rescale else (0.01, 0.1), rescale=rescale)
     flags = GRAD_FOLD_ROOT_FREQS if fold else 0
-    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e, engine_from_problem(pb, rescale=RESCALE_NEVER) as full:
+    mode = RESCALE_ALWAYS if rescale else RESCALE_NEVER
+    with engine_from_problem(pb, rescale=mode) as e, engine_from_problem(pb, rescale=mode) as full:
         with pytest.raises(EngineError):
             e.branch_log_likelihood(0, 0.1)  # partials are not resident yet
         e.set_keep_partials(True)
@@ -674,7 +677,7 @@ def test_single_branch_evaluation(T, P, C, fold):
             l, d1, d2 = e.branch_log_likelihood(n, t0)
             if not fold:  # (the folded form is the reference's inexact arithmetic for non-uniform pi: only self-consistency below)
                 assert abs(l - lnl0) <= 1e-11 * abs(lnl0)
-                assert abs(d1 - bg[n]) <= 1e-9 * max(1.0, abs(bg[n]))
+                assert abs(d1 - bg[n]) <= 1e-9 * max(1.0, abs(bg).max())
             for t in (0.5 * t0, 1.7 * t0, 0.3):
                 lt, d1t, d2t = e.branch_log_likelihood(n, t)
                 if not fold:
