@@ -85,6 +85,18 @@ int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states);
 int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials);
 int phyamd_set_pattern_weights(phyamd_engine *e, const double *weights /* [P] */);
 
+/* new_SitePattern (sitepattern.c:186-251) on the device: de-duplicates the columns of an alignment and returns them in the
+ * reference's order -- the iteration order of its chained hash table (hashtable.c: 193 buckets, growth through the prime
+ * table at load 0.65, chains prepended and reversed by growth), rebuilt from per-column hashes and first-occurrence ranks
+ * with radix sorts instead of T*L sequential insertions.  Engine-independent and synchronous.
+ *   rows[taxon_count]: host pointers to site_count bytes each (state codes; or raw one-byte symbols when symbol_codes is
+ *   given: symbol_codes[256] maps a symbol to its state code, datatype.c:55-89);
+ *   patterns: host buffer of taxon_count * site_count bytes, filled as [taxon][pattern] with *pattern_count columns;
+ *   weights: host buffer of site_count doubles.
+ * PHYAMD_EUNSUPPORTED if two different columns collide in both 32-bit hashes (nothing is folded: compress on the host). */
+int phyamd_compress_patterns(int device /* -1: current */, int32_t taxon_count, int64_t site_count, const uint8_t *const *rows,
+                             const uint8_t *symbol_codes /* [256] or NULL */, int32_t *pattern_count, uint8_t *patterns, double *weights);
+
 /* --- tree: Tree/Node ids, Node_left/right (tree.c:183-224) --- */
 int phyamd_set_topology(phyamd_engine *e, const int32_t *left, const int32_t *right /* [2T-1], -1 for tips */, int root);
 /* branch length per node id, already multiplied by the clock rate for time trees

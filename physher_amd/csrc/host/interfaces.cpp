@@ -426,7 +426,16 @@ TreeLikelihoodInterface::TreeLikelihoodInterface(const std::vector<std::pair<std
 		names.push_back(kv.first);
 		seqs.push_back(kv.second);
 	}
-	impl_->patterns = phyamd::compress_patterns(dt, names, seqs);  // new_SitePattern (physher.cpp:569-577)
+	// new_SitePattern (physher.cpp:569-577); long alignments on the device (same patterns in the same order)
+	bool compressed = false;
+	if (!seqs.empty() && seqs[0].size() / (size_t)dt.symbol_length >= phyamd::kDeviceCompressionSites) {
+		try {
+			impl_->patterns = phyamd::compress_patterns_device(dt, names, seqs);
+			compressed = true;
+		} catch (const phyamd::Error &) {  // two columns collided in both hashes: the sequential table is exact by construction
+		}
+	}
+	if (!compressed) impl_->patterns = phyamd::compress_patterns(dt, names, seqs);
 	Init(use_tip_states);
 }
 

@@ -83,6 +83,11 @@ struct Patterns {
 
 // new_SitePattern (sitepattern.c:186-251): de-duplicate columns, bit-exact in the reference's hashtable order
 Patterns compress_patterns(const DataType &dt, const std::vector<std::string> &names, const std::vector<std::string> &sequences);
+// the same result from the device (phyamd_compress_patterns: hashing, grouping and the table order by radix sorts); throws
+// if the device path declines (hash collision) -- callers fall back to compress_patterns
+Patterns compress_patterns_device(const DataType &dt, const std::vector<std::string> &names, const std::vector<std::string> &sequences);
+// alignments with at least this many sites are compressed on the device by the likelihood wrapper
+constexpr size_t kDeviceCompressionSites = 50000;
 
 // ---------------------------------------------------------------------------------------------
 // Substitution models (reference: substmodel.c, gtr.c, hky.c, jc69.c, gensubst.c, eigen.c)

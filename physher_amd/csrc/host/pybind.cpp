@@ -213,6 +213,15 @@ PYBIND11_MODULE(_phycpp_amd, m) {
 		phyamd::Patterns p = phyamd::compress_patterns(dt, names, seqs);
 		return py::make_tuple(py::array_t<unsigned char>({(py::ssize_t)p.taxon_count, (py::ssize_t)p.pattern_count}, p.states.data()), vec(p.weights));
 	});
+	m.def("compress_patterns_device", [](const std::string &datatype, const std::vector<std::string> &names, const std::vector<std::string> &seqs) {
+		phyamd::DataType dt;
+		if (datatype == "nucleotide") dt.kind = phyamd::DataTypeKind::Nucleotide, dt.state_count = 4;
+		else if (datatype == "aa") dt.kind = phyamd::DataTypeKind::AminoAcid, dt.state_count = 20;
+		else if (datatype == "codon") dt.kind = phyamd::DataTypeKind::Codon, dt.state_count = 61, dt.symbol_length = 3;
+		else throw phyamd::Error("unknown datatype " + datatype);
+		phyamd::Patterns p = phyamd::compress_patterns_device(dt, names, seqs);
+		return py::make_tuple(py::array_t<unsigned char>({(py::ssize_t)p.taxon_count, (py::ssize_t)p.pattern_count}, p.states.data()), vec(p.weights));
+	});
 	m.def("gamma_quantile", &phyamd::gamma_quantile);
 	m.def("reg_lower_gamma", &phyamd::reg_lower_gamma);
 }

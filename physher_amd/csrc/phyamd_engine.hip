@@ -17,6 +17,7 @@
 // gfx950 only; no CUDA/compat paths.
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -29,7 +30,7 @@
 
 #include "physher_amd.h"
 
-#define PHYAMD_ABI_VERSION 2
+#define PHYAMD_ABI_VERSION 3
 
 namespace {
 
@@ -100,6 +101,7 @@ struct NodeOp {
 #include "phyamd_level4.inc"
 #include "phyamd_walk4.inc"
 #include "phyamd_general.inc"
+#include "phyamd_patterns.inc"
 
 }  // namespace
 
@@ -1750,6 +1752,11 @@ int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, doub
 	if (d1) *d1 = e->h_result[1];
 	if (d2) *d2 = e->h_result[2];
 	return PHYAMD_OK;
+}
+
+int phyamd_compress_patterns(int device, int32_t taxon_count, int64_t site_count, const uint8_t *const *rows, const uint8_t *symbol_codes,
+                             int32_t *pattern_count, uint8_t *patterns, double *weights) {
+	return compress_patterns_device(device, taxon_count, site_count, rows, symbol_codes, pattern_count, patterns, weights);
 }
 
 int phyamd_root_invariant_term(phyamd_engine *e, double *out) {
