@@ -398,6 +398,48 @@ static void check(int rc) {
 	if (rc != PHYAMD_OK) throw Error(std::string("physher_amd engine: ") + phyamd_last_error());
 }
 
+// (lives here, not in patterns.cpp: that file stays free of the engine so the host sanitiser build needs no device library)
+Patterns compress_patterns_device(const DataType &dt, const std::vector<std::string> &names, const std::vector<std::string> &sequences) {
+	const int T = (int)sequences.size();
+	if (T == 0 || names.size() != sequences.size()) throw Error("alignment needs one name per sequence");
+	const size_t len = sequences[0].size();
+	for (const auto &s : sequences)
+		if (s.size() != len) throw Error("sequences are not aligned (different lengths)");
+	const int step = dt.symbol_length;
+	const size_t sites = len / step;
+	if (sites == 0) throw Error("empty alignment");
+	std::vector<const uint8_t *> rows(T);
+	std::vector<uint8_t> lut, coded;
+	if (step == 1) {  // one-byte symbols: the device translates through the data type's table
+		lut.resize(256);
+		char sym[2] = {0, 0};
+		for (int ch = 0; ch < 256; ch++) {
+			sym[0] = (char)ch;
+			lut[ch] = (uint8_t)dt.encode(sym);
+		}
+		for (int t = 0; t < T; t++) rows[t] = reinterpret_cast<const uint8_t *>(sequences[t].data());
+	} else {  // codons and other multi-character symbols are coded here
+		coded.resize((size_t)T * sites);
+		for (int t = 0; t < T; t++) {
+			for (size_t s = 0; s < sites; s++) coded[(size_t)t * sites + s] = (uint8_t)dt.encode(sequences[t].data() + s * step);
+			rows[t] = &coded[(size_t)t * sites];
+		}
+	}
+	Patterns p;
+	p.taxon_count = T;
+	p.site_count = (int)sites;
+	p.names = names;
+	p.states.resize((size_t)T * sites);
+	p.weights.resize(sites);
+	int32_t count = 0;
+	if (phyamd_compress_patterns(-1, T, (int64_t)sites, rows.data(), lut.empty() ? nullptr : lut.data(), &count, p.states.data(), p.weights.data()) != PHYAMD_OK)
+		throw Error(phyamd_last_error());
+	p.pattern_count = count;
+	p.states.resize((size_t)T * count);
+	p.weights.resize(count);
+	return p;
+}
+
 }  // namespace phyamd
 
 // state counts the engine has kernels for; other counts are padded up with states nothing can enter or leave

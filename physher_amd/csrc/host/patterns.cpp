@@ -3,7 +3,6 @@
 #include <cstring>
 
 #include "phyamd_host.hpp"
-#include "physher_amd.h"
 
 namespace phyamd {
 
@@ -163,47 +162,6 @@ Patterns compress_patterns(const DataType &dt, const std::vector<std::string> &n
 			for (int t = 0; t < T; t++) p.states[(size_t)t * p.pattern_count + k] = cols[(size_t)entries[e].site * T + t];
 			k++;
 		}
-	return p;
-}
-
-Patterns compress_patterns_device(const DataType &dt, const std::vector<std::string> &names, const std::vector<std::string> &sequences) {
-	const int T = (int)sequences.size();
-	if (T == 0 || names.size() != sequences.size()) throw Error("alignment needs one name per sequence");
-	const size_t len = sequences[0].size();
-	for (const auto &s : sequences)
-		if (s.size() != len) throw Error("sequences are not aligned (different lengths)");
-	const int step = dt.symbol_length;
-	const size_t sites = len / step;
-	if (sites == 0) throw Error("empty alignment");
-	std::vector<const uint8_t *> rows(T);
-	std::vector<uint8_t> lut, coded;
-	if (step == 1) {  // one-byte symbols: the device translates through the data type's table
-		lut.resize(256);
-		char sym[2] = {0, 0};
-		for (int ch = 0; ch < 256; ch++) {
-			sym[0] = (char)ch;
-			lut[ch] = (uint8_t)dt.encode(sym);
-		}
-		for (int t = 0; t < T; t++) rows[t] = reinterpret_cast<const uint8_t *>(sequences[t].data());
-	} else {  // codons and other multi-character symbols are coded here
-		coded.resize((size_t)T * sites);
-		for (int t = 0; t < T; t++) {
-			for (size_t s = 0; s < sites; s++) coded[(size_t)t * sites + s] = (uint8_t)dt.encode(sequences[t].data() + s * step);
-			rows[t] = &coded[(size_t)t * sites];
-		}
-	}
-	Patterns p;
-	p.taxon_count = T;
-	p.site_count = (int)sites;
-	p.names = names;
-	p.states.resize((size_t)T * sites);
-	p.weights.resize(sites);
-	int32_t count = 0;
-	if (phyamd_compress_patterns(-1, T, (int64_t)sites, rows.data(), lut.empty() ? nullptr : lut.data(), &count, p.states.data(), p.weights.data()) != PHYAMD_OK)
-		throw Error(phyamd_last_error());
-	p.pattern_count = count;
-	p.states.resize((size_t)T * count);
-	p.weights.resize(count);
 	return p;
 }
 
