@@ -110,6 +110,18 @@ int phyamd_set_branch_length(phyamd_engine *e, int node, double length);
 /* SingleTreeLikelihood_update_all_nodes (treelikelihood.c:1737-1771): force the next evaluation to recompute every node. */
 int phyamd_update_all_nodes(phyamd_engine *e);
 
+/* MCMC store / restore (_singleTreeLikelihood_store, _treelikelihood_handle_restore: treelikelihood.c:116-161; the
+ * current/stored index pairs of allocate_storage, :947-1005).  phyamd_store evaluates anything pending and remembers the
+ * engine's state: branch lengths, eigen system, frequencies, category rates and proportions, lnL, and the stored partials --
+ * the first call gives every stored node a second slot (lower-partial memory doubles); evaluations after a store never
+ * write the slot the stored state lives in.  phyamd_restore brings that state back without recomputing the tree: nodes
+ * point at their stored slots again and only the root is re-integrated on the next evaluation.  The caller does NOT send
+ * the old parameters again after a restore.  Not covered: topology, tip data, pattern weights, explicit node matrices
+ * (changing the first three drops the stored state; restore then returns PHYAMD_EINVAL).  If slots were reassigned in between
+ * (phyamd_set_keep_partials, the lazy rescaling switch) the restored parameters are simply recomputed in full. */
+int phyamd_store(phyamd_engine *e);
+int phyamd_restore(phyamd_engine *e);
+
 /* --- models: SubstitutionModel eigen system + frequencies, SiteModel rates/proportions --- */
 /* eval[S], evec[S][S], ivec[S][S]: m->eigendcmp after update_eigen_system (substmodel.c:1092-1115);
  * P(t) = |evec diag(exp(eval t)) ivec| is formed on the device (substmodel.c:518-557). */

@@ -72,6 +72,8 @@ SYMBOLS = [
     ("phyamd_set_keep_partials", C.c_int, [_P, C.c_int]),
     ("phyamd_set_profiling", C.c_int, [_P, C.c_int]),
     ("phyamd_get_profile", C.c_int, [_P, C.POINTER(Profile)]),
+    ("phyamd_store", C.c_int, [_P]),
+    ("phyamd_restore", C.c_int, [_P]),
     ("phyamd_compress_patterns", C.c_int, [C.c_int, C.c_int32, C.c_int64, _P, _P, C.POINTER(C.c_int32), _P, _P]),
 ]
 

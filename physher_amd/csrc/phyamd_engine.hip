@@ -133,6 +133,20 @@ struct phyamd_engine {
 	const std::vector<int> *act_level_off = nullptr;
 	NodeOp *act_lower_ops = nullptr;
 	bool level_upper_needed = false;  // a level-schedule pre-order pass (parameter gradients) has been requested
+	// MCMC store / restore (_singleTreeLikelihood_store, _treelikelihood_handle_restore: treelikelihood.c:116-161): after a
+	// store every stored node has two slots (slot = core index, + core_count for the second); an evaluation never writes the
+	// slot the stored state lives in, so restore is an index flip (plus re-integrating the root), not a recomputation
+	struct Stored {
+		bool valid = false;
+		std::vector<double> lengths, model, freqs, rates, props;
+		std::vector<int32_t> core_index;  // node -> slot of the stored state
+		bool have_eigen = false, scaling_on = false;
+		unsigned long epoch = 0;
+		double lnl = 0.0;
+	} stored;
+	unsigned long schedule_epoch = 0;  // bumped whenever slots are reassigned from scratch
+	bool two_slots = false;            // d_lower / d_lscale hold 2 * core_count slots
+	bool force_root = false;           // the root's outputs (lnL_k, w_k / L_k, lnL) belong to a discarded state
 	bool walk_params_on = true;  // parameter gradients through the tree walk (PHYAMD_WALK_PARAMS = 0: level kernels)
 	bool walk_lower_on = true, walk_upper_on = true;  // A/B switches (PHYAMD_WALK_LOWER / PHYAMD_WALK_UPPER = 0)
 	bool walk_enabled = true, walking = false;  // tree-walk kernels (4 states, unscaled, not keep_partials)
@@ -485,7 +499,7 @@ int build_schedule(phyamd_engine *e) {
 }
 
 int ensure_lower_storage(phyamd_engine *e) {
-	const size_t need = (size_t)std::max(1, e->core_count);
+	const size_t need = (size_t)std::max(1, e->core_count) * (e->two_slots ? 2 : 1);
 	if (e->d_lower && e->lower_alloc_cores >= need) return PHYAMD_OK;
 	dev_free(e, &e->d_lower, e->lower_alloc_cores * node_partial_doubles(e));
 	dev_free(e, &e->d_lscale, e->lower_alloc_cores * (size_t)e->P);
@@ -494,6 +508,16 @@ int ensure_lower_storage(phyamd_engine *e) {
 	if (rc) return rc;
 	e->lower_alloc_cores = need;
 	return PHYAMD_OK;
+}
+
+// after slots moved (store / restore): the ops carry slot indices
+void refresh_op_cores(phyamd_engine *e) {
+	for (std::vector<NodeOp> *ops : {&e->lower_ops, &e->upper_ops, &e->walk_lower_ops, &e->walk_upper_ops})
+		for (NodeOp &op : *ops) {
+			op.core_parent = e->core_index[op.parent];
+			op.core_left = e->core_index[op.left];
+			op.core_right = e->core_index[op.right];
+		}
 }
 
 int upload_schedule(phyamd_engine *e) {
@@ -823,9 +847,11 @@ int launch_lower_gen(phyamd_engine *e) {
 	if ((rc = allow_big_lds(k_lower_gen<RT, KT, true, SCALE>, lds)) || (rc = allow_big_lds(k_lower_gen<RT, KT, false, SCALE>, lds))) return rc;
 	if (SCALE && (rc = ensure_gen_scale_storage(e))) return rc;
 	const int pblocks = (e->P + 255) / 256;
+	int launched = 0;
 	for (int lv = 0; lv < levels; lv++) {
 		const int off = level_off[lv], cnt = level_off[lv + 1] - off;
 		if (cnt == 0) continue;
+		launched++;
 		dim3 grid(e->nblk, cnt, e->C);
 		const bool is_root = lv == levels - 1;
 		if (is_root)
@@ -841,7 +867,7 @@ int launch_lower_gen(phyamd_engine *e) {
 	const double *lscale_root = SCALE ? e->d_lscale + (size_t)e->core_index[e->root] * e->P : nullptr;
 	hipLaunchKernelGGL(k_root_finish, dim3(e->nblk_root), dim3(256), 0, e->stream, e->P, e->C, e->d_Lc, e->d_weights, lscale_root, e->d_plk, e->d_wl, e->d_lnl_part);
 	HIP_TRY(hipGetLastError());
-	e->prof.lower_launches = levels;
+	e->prof.lower_launches = launched;
 	return PHYAMD_OK;
 }
 
@@ -911,6 +937,7 @@ int rebuild_schedule(phyamd_engine *e) {
 	if ((rc = build_schedule(e))) return rc;
 	if ((rc = upload_schedule(e))) return rc;
 	if ((rc = ensure_lower_storage(e))) return rc;
+	e->schedule_epoch++;  // slots start over: a stored state no longer maps onto them
 	e->upper_valid = false;
 	e->all_dirty = true;
 	e->lower_valid = false;
@@ -933,20 +960,38 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 	e->act_level_off = &e->lower_level_off;
 	e->act_lower_ops = e->d_lower_ops;
 	e->incremental_pass = false;
-	if (e->lower_valid && !e->all_dirty) {
+	const bool incremental = e->lower_valid && !e->all_dirty;
+	if (incremental && e->changed.empty() && !e->force_root) {  // nothing changed: d_result[0] still holds lnL
+		record(e, 2);
+		e->prof.lower_launches = 0;
+		e->prof_pending = e->profiling;
+		e->prof_with_upper = false;
+		return PHYAMD_OK;
+	}
+	std::vector<uint8_t> dirty;
+	if (incremental) {
 		// only single branch lengths changed since the stored partials were computed: recompute the core nodes on the paths
 		// from those branches to the root, in level order (update_nodes[] semantics, treelikelihood.c:73-114, 1645-1734)
-		if (e->changed.empty()) {  // nothing changed: d_result[0] still holds lnL
-			record(e, 2);
-			e->prof.lower_launches = 0;
-			e->prof_pending = e->profiling;
-			e->prof_with_upper = false;
-			return PHYAMD_OK;
-		}
-		std::vector<uint8_t> dirty(e->N, 0);
+		dirty.assign(e->N, 0);
 		for (int n : e->changed)
 			for (int a = e->parent[n]; a >= 0 && !dirty[a]; a = e->parent[a])
 				if (e->core_index[a] >= 0) dirty[a] = 1;  // fused fringe nodes are recomputed inside their first stored ancestor
+		if (e->force_root) dirty[e->root] = 1;
+	}
+	if (e->stored.valid && e->stored.epoch == e->schedule_epoch) {
+		// nodes about to be written leave the slot the stored state lives in (current_partials_indexes flip, treelikelihood.c:1693-1700)
+		bool moved = false;
+		for (int n = e->T; n < e->N; n++)
+			if (e->core_index[n] >= 0 && (!incremental || dirty[n]) && e->core_index[n] == e->stored.core_index[n]) {
+				e->core_index[n] += e->core_index[n] < e->core_count ? e->core_count : -e->core_count;
+				moved = true;
+			}
+		if (moved) {
+			refresh_op_cores(e);
+			if ((rc = upload_schedule(e))) return rc;
+		}
+	}
+	if (incremental) {
 		e->inc_ops.clear();
 		e->inc_level_off.assign(1, 0);
 		for (size_t lv = 0; lv + 1 < e->lower_level_off.size(); lv++) {
@@ -981,6 +1026,7 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 	e->incremental_pass = false;
 	e->lower_valid = true;
 	e->all_dirty = false;
+	e->force_root = false;
 	e->changed.clear();
 	record(e, 2);
 	e->prof_pending = e->profiling;
@@ -1361,6 +1407,7 @@ int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states) {
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->tip_set[tip] = 1;
 	e->all_dirty = true;
+	e->stored.valid = false;
 	return PHYAMD_OK;
 }
 
@@ -1415,6 +1462,7 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->tip_set[tip] = 1;
 	e->all_dirty = true;
+	e->stored.valid = false;
 	return PHYAMD_OK;
 }
 
@@ -1427,6 +1475,7 @@ int phyamd_set_pattern_weights(phyamd_engine *e, const double *weights) {
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_weights = true;
 	e->all_dirty = true;
+	e->stored.valid = false;
 	return PHYAMD_OK;
 }
 
@@ -1452,6 +1501,10 @@ int phyamd_set_topology(phyamd_engine *e, const int32_t *left, const int32_t *ri
 	e->have_topology = true;
 	e->matrices_dirty = true;
 	e->upper_valid = false;
+	e->all_dirty = true;  // every partial belongs to the old tree
+	e->lower_valid = false;
+	e->schedule_epoch++;
+	e->stored.valid = false;  // topology is not part of phyamd_store
 	return PHYAMD_OK;
 }
 
@@ -1483,6 +1536,81 @@ int phyamd_set_branch_length(phyamd_engine *e, int node, double length) {
 	e->matrices_dirty = true;  // all P(t) are re-formed (microseconds); only the partials above `node` are recomputed
 	e->changed.push_back(node);
 	e->upper_valid = false;
+	return PHYAMD_OK;
+}
+
+int phyamd_store(phyamd_engine *e) {
+	CHECK_ENGINE(e);
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	for (uint8_t x : e->explicit_host)
+		if (x) return fail(PHYAMD_EUNSUPPORTED, "phyamd_store does not cover explicit node matrices");
+	if ((rc = run_lower(e, true))) return rc;  // the state that is stored is an evaluated one (a no-op when nothing is pending)
+	if (!e->two_slots) {  // first store: a second slot per stored node (allocate_storage(tlk, 1), treelikelihood.c:977-1003), contents kept
+		const size_t npd = node_partial_doubles(e), old_slots = e->lower_alloc_cores, want = (size_t)std::max(1, e->core_count) * 2;
+		double *lower = nullptr, *lscale = nullptr;
+		HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lower), want * npd * sizeof(double)));
+		HIP_TRY(hipMemcpyAsync(lower, e->d_lower, old_slots * npd * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+		if (e->d_lscale) {
+			HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lscale), want * e->P * sizeof(double)));
+			HIP_TRY(hipMemcpyAsync(lscale, e->d_lscale, old_slots * e->P * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+		}
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		e->device_bytes += (int64_t)(want * npd * sizeof(double)) + (lscale ? (int64_t)(want * e->P * sizeof(double)) : 0);
+		dev_free(e, &e->d_lower, old_slots * npd);
+		if (e->d_lscale) dev_free(e, &e->d_lscale, old_slots * (size_t)e->P);
+		e->d_lower = lower;
+		e->d_lscale = lscale;
+		e->lower_alloc_cores = want;
+		e->two_slots = true;
+	}
+	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	auto &st = e->stored;
+	st.lnl = e->h_result[0];
+	st.lengths = e->lengths;
+	st.model = e->model;
+	st.freqs = e->freqs;
+	st.rates = e->rates;
+	st.props = e->props;
+	st.have_eigen = e->have_eigen;
+	st.scaling_on = e->scaling_on;
+	st.core_index = e->core_index;
+	st.epoch = e->schedule_epoch;
+	st.valid = true;
+	return PHYAMD_OK;
+}
+
+int phyamd_restore(phyamd_engine *e) {
+	CHECK_ENGINE(e);
+	if (!e->stored.valid) return fail(PHYAMD_EINVAL, "nothing is stored (phyamd_store has not been called, or tree / data changed since)");
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	const phyamd_engine::Stored st = e->stored;  // the setters below write the engine's own copies
+	const int S = e->S;
+	if (st.have_eigen && (rc = phyamd_set_eigen(e, st.model.data(), st.model.data() + S, st.model.data() + S + S * S))) return rc;
+	if ((rc = phyamd_set_frequencies(e, st.freqs.data()))) return rc;
+	if ((rc = phyamd_set_category_rates(e, st.rates.data(), st.props.data()))) return rc;
+	if ((rc = phyamd_set_branch_lengths(e, st.lengths.data()))) return rc;
+	e->changed.clear();
+	e->upper_valid = false;
+	if (st.epoch == e->schedule_epoch && st.scaling_on == e->scaling_on && e->two_slots) {
+		// the stored partials are still in their slots: point the nodes back at them (treelikelihood.c:116-124) and
+		// re-integrate the root, whose per-pattern outputs belong to the discarded state
+		bool moved = false;
+		for (int n = e->T; n < e->N; n++)
+			if (e->core_index[n] != st.core_index[n]) {
+				e->core_index[n] = st.core_index[n];
+				moved = true;
+			}
+		if (moved) {
+			refresh_op_cores(e);
+			if ((rc = upload_schedule(e))) return rc;
+		}
+		e->all_dirty = false;
+		e->lower_valid = true;
+		e->force_root = true;
+	}  // else: slots were reassigned since (schedule rebuilt, rescaling switched on): the restored parameters are recomputed in full
 	return PHYAMD_OK;
 }
 

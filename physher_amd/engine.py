@@ -171,6 +171,14 @@ class Engine:
         self._check(self._lib.phyamd_branch_log_likelihood(self._h, int(node), float(length), C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def store(self):
+        """Remember the current (evaluated) state: parameters, lnL and partials (MCMC store)."""
+        self._check(self._lib.phyamd_store(self._h))
+
+    def restore(self):
+        """Back to the stored state without recomputing the tree (MCMC reject)."""
+        self._check(self._lib.phyamd_restore(self._h))
+
     def synchronize(self):
         self._check(self._lib.phyamd_synchronize(self._h))
 

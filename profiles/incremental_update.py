@@ -27,5 +27,16 @@ for n in rng.choice([i for i in range(2 * T - 1) if i != tree.root], size=12, re
     out["single"].append({"node": int(n), "ms": dt * 1e3, "launches": e.profile()["lower_launches"], "kernel_ms": e.profile()["lower_ms"]})
 e.update_all_nodes(); lchk = e.log_likelihood()
 out["check_rel"] = abs(l - lchk) / abs(lchk)
+# MCMC store / restore: propose one branch, evaluate, reject
+t0 = time.perf_counter(); e.store(); out["first_store_ms"] = (time.perf_counter() - t0) * 1e3   # allocates the second slots
+out["device_bytes_after_store"] = e.profile()["device_bytes"]
+out["mcmc"] = []
+for n in rng.choice([i for i in range(2 * T - 1) if i != tree.root], size=8, replace=False):
+    t0 = time.perf_counter(); e.store(); ts = time.perf_counter() - t0
+    t0 = time.perf_counter(); e.set_branch_length(int(n), bl[n] * 1.3); lp = e.log_likelihood(); tp = time.perf_counter() - t0
+    t0 = time.perf_counter(); e.restore(); lb = e.log_likelihood(); tr = time.perf_counter() - t0
+    out["mcmc"].append({"node": int(n), "store_ms": ts * 1e3, "propose_eval_ms": tp * 1e3, "restore_eval_ms": tr * 1e3,
+                        "restore_launches": e.profile()["lower_launches"], "restored_rel": abs(lb - lchk) / abs(lchk)})
+out["median_restore_eval_ms"] = float(np.median([m["restore_eval_ms"] for m in out["mcmc"]]))
 out["median_single_ms"] = float(np.median([s["ms"] for s in out["single"]]))
 print(json.dumps(out))

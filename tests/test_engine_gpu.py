@@ -697,6 +697,80 @@ def test_single_branch_evaluation(S, T, P, C, fold, rescale):
             e.branch_log_likelihood(0, 0.5)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# f.4: MCMC store / restore
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,T,P,C,rescale,keep", [(4, 40, 500, 4, RESCALE_NEVER, False), (4, 25, 130, 2, RESCALE_NEVER, True),
+                                                  (4, 70, 200, 4, RESCALE_ALWAYS, False), (20, 15, 60, 2, RESCALE_NEVER, False),
+                                                  (61, 30, 20, 1, RESCALE_ALWAYS, False)])
+def test_store_restore_mcmc_walk(S, T, P, C, rescale, keep):
+    """A short Metropolis-style walk: proposals change one branch, a few branches, every branch, or the category rates; each
+    is evaluated, then accepted (store) or rejected (restore).  Every evaluation equals a fresh full recomputation of the
+    same parameters; after a restore the stored lnL and gradient come back and only the root is re-integrated
+    (_singleTreeLikelihood_store / _treelikelihood_handle_restore, treelikelihood.c:116-161)."""
+    forced = rescale == RESCALE_ALWAYS
+    pb = random_problem(T, P, C, seed=7000 + S + T, S=S, gaps=0.03, bl=(0.3, 0.9) if forced else (0.01, 0.1), rescale=1 if forced else 0)
+    rng = np.random.default_rng(S + T)
+    with engine_from_problem(pb, rescale=rescale) as e, engine_from_problem(pb, rescale=rescale) as full:
+        with pytest.raises(EngineError):
+            e.restore()  # nothing stored yet
+        if keep:
+            e.set_keep_partials(True)
+        e.set_profiling(True)
+        bl, rates = pb.branch_lengths.copy(), pb.cat_rates.copy()
+        lnl_cur, _ = e.gradient()
+        e.store()
+        non_root = [n for n in range(pb.N) if n != pb.root]
+
+        def reference(bl_, rates_):
+            full.set_category_rates(rates_, pb.cat_props)
+            full.set_branch_lengths(bl_)
+            return full.gradient()
+
+        accepted = rejected = 0
+        for step in range(14):
+            kind = ["one", "few", "all", "rates"][step % 4]
+            nbl, nrates = bl.copy(), rates.copy()
+            if kind == "one":
+                n = int(rng.choice(non_root))
+                nbl[n] *= rng.uniform(0.5, 2.0)
+                e.set_branch_length(n, nbl[n])
+            elif kind == "few":
+                for n in rng.choice(non_root, size=3, replace=False):
+                    nbl[n] *= rng.uniform(0.5, 2.0)
+                    e.set_branch_length(int(n), nbl[n])
+            elif kind == "all":
+                nbl = bl * rng.uniform(0.8, 1.25, size=pb.N)
+                e.set_branch_lengths(nbl)
+            else:
+                nrates = rates * rng.uniform(0.8, 1.25, size=C)
+                e.set_category_rates(nrates, pb.cat_props)
+            lnl_new = e.log_likelihood()
+            ref_lnl, ref_cg = reference(nbl, nrates)
+            assert abs(lnl_new - ref_lnl) <= 1e-12 * abs(ref_lnl), (step, kind)
+            if step % 3 == 0:  # accept
+                _, cg = e.gradient()
+                assert np.abs(cg - ref_cg).max() <= 1e-10 * max(1.0, np.abs(ref_cg).max())
+                bl, rates, lnl_cur = nbl, nrates, lnl_new
+                e.store()
+                accepted += 1
+            else:  # reject
+                e.restore()
+                back = e.log_likelihood()
+                assert abs(back - lnl_cur) <= 1e-13 * abs(lnl_cur), (step, kind)
+                assert e.profile()["lower_launches"] <= 1  # the root alone
+                ref_lnl, ref_cg = reference(bl, rates)
+                lnl_g, cg = e.gradient()
+                assert abs(lnl_g - ref_lnl) <= 1e-12 * abs(ref_lnl)
+                assert np.abs(cg - ref_cg).max() <= 1e-10 * max(1.0, np.abs(ref_cg).max())
+                rejected += 1
+        assert accepted >= 4 and rejected >= 8
+        # data changes drop the stored state
+        e.set_pattern_weights(pb.weights)
+        with pytest.raises(EngineError):
+            e.restore()
+
+
 def test_root_terms_agree_between_rescaled_and_unscaled_evaluations():
     """The +I root term and the frequency root term form L_k from the root partial itself, so they are the same numbers
     whether the evaluation was rescaled or not."""
