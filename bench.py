@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rescale", choices=("auto", "always", "never"), default="auto",
                     help="rescaling policy (auto = the reference's lazy switch; always: NOT the headline configuration, measures the rescaled kernels)")
+    ap.add_argument("--max-device-gb", type=float, default=0.0,
+                    help="NOT the headline configuration: cap the engine's device memory; below the working set the patterns are "
+                         "processed in tiles through one set of partial arrays (per-kernel roofline figures then describe the last tile)")
     ap.add_argument("--subst-gradient", action="store_true",
                     help="NOT the headline metric: each step also yields d lnL / d(5 GTR rates, 4 frequencies) (SURVEY 8f.1) in the same two passes")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -245,7 +248,7 @@ def main():
 
     stream = torch.cuda.current_stream(device)
     eng = Engine(T, Pl, S, C, device=local_rank, rescale={"auto": RESCALE_AUTO, "always": RESCALE_ALWAYS, "never": RESCALE_NEVER}[args.rescale],
-                 stream=stream.cuda_stream)
+                 stream=stream.cuda_stream, max_device_bytes=int(args.max_device_gb * 1e9))
     eng.set_topology(tree.left, tree.right, tree.root)
     eng.set_branch_lengths(tree.length)
     eng.set_eigen(ev, U, Ui)
@@ -336,7 +339,7 @@ def main():
             "config": {"workload": f"{wl['name']}, {T} taxa x {P} patterns x {S} states x {C} categories, unrooted, full recompute per eval "
                                    f"(BASELINE configs[{int(args.config[3]) - 1}] shape; {Pl} patterns on this rank)",
                        "taxa": T, "patterns": P, "categories": C, "states": S, "patterns_per_gpu": Pl, "lnL": lnl,
-                       "rescaling": eng.rescaling, "device_bytes": p["device_bytes"]},
+                       "rescaling": eng.rescaling, "device_bytes": p["device_bytes"], "tiles": p["tiles"]},
             "roofline": {"bound": "hbm", "kernel": f"k_upper{kern} (pre-order pass + fused branch gradient)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
@@ -359,6 +362,9 @@ def main():
                                        "frac": None if tf is None else tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": fl}
             if S > 20:
                 out["roofline"]["bound"] = "mfma"
+        if p["tiles"] > 1:  # the engine's per-kernel timings describe the last tile only: no roofline claim for a tiled run
+            out["roofline"] = {"bound": "hbm", "kernel": out["roofline"]["kernel"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                               "traffic": None, "note": f"patterns processed in {p['tiles']} tiles (--max-device-gb): per-launch figures not comparable"}
         if world == 1 and not args.no_cpu_baseline and S == 4:
             cb = cpu_baseline(tree, states, weights, cat_rates, args.cpu_sample_patterns, args.cpu_budget_s)
             scaled = cb["t_eval"] * (P / cb["patterns"])

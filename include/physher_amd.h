@@ -63,8 +63,13 @@ typedef struct {
 	int32_t category_count; /* C */
 	int32_t device;         /* HIP device ordinal; -1 = current device */
 	int32_t rescale;        /* PHYAMD_RESCALE_* (all state counts) */
-	int64_t max_device_bytes; /* 0 = no cap.  A cap below the engine's need makes phyamd_create fail with PHYAMD_ENOMEM
-	                             (processing the patterns in tiles that fit is not built yet: shard across engines instead) */
+	int64_t max_device_bytes; /* 0 = no cap.  Below the (estimated) working set of all patterns the engine processes them in
+	                             tiles through ONE set of partial arrays: tip data, weights and per-pattern lnL of all tiles
+	                             stay resident, per-tile sums are added in tile order (phyamd_profile.tiles tells how many).
+	                             lnL, gradients and parameter gradients work as usual; calls that need resident partials
+	                             (phyamd_get_partials, phyamd_set_keep_partials, phyamd_store, phyamd_branch_log_likelihood,
+	                             phyamd_root_invariant_term) return PHYAMD_EUNSUPPORTED, and every evaluation recomputes every
+	                             tile.  PHYAMD_ENOMEM if even a 256-pattern tile does not fit. */
 	void *stream;           /* hipStream_t to run on, NULL = engine-owned stream */
 } phyamd_config;
 
@@ -157,7 +162,7 @@ int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out);
 int phyamd_root_invariant_term(phyamd_engine *e, double *out);
 
 /* --- substitution-model gradient: calculate_dlnl_dQ (treelikelihood.c:2337-2583) --- */
-#define PHYAMD_MAX_PARAMETERS 64
+#define PHYAMD_MAX_PARAMETERS 2048 /* a 61-state symmetric model has 1830 rates + 61 frequencies */
 /* dQ [count][S][S]: derivative of the (normalised) rate matrix with respect to each parameter, what the reference's
  * m->dQ holds after _gtr_dQdp / _hky_dQdp / _general_dQdp (gtr.c:256-326, hky.c:493-541, gensubst.c:216-279).  The engine
  * forms dP/dtheta = U ((U^-1 dQ U) o F(t)) U^-1 per branch and category itself (dPdp_with_dQdp, substmodel.c:469-489).

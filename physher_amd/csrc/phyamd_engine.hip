@@ -144,6 +144,12 @@ struct phyamd_engine {
 		unsigned long epoch = 0;
 		double lnl = 0.0;
 	} stored;
+	// pattern tiling (cfg.max_device_bytes): P = patterns per tile (what every kernel sees), Ptot = the caller's count;
+	// tip data, weights and per-pattern lnL of all tiles stay resident, the partial arrays are reused tile after tile
+	int Ptot = 0, tiles = 1;
+	bool tiled_root_term = false;     // d_result holds the summed root frequency term of a tiled parameter gradient
+	uint8_t *d_tip_all = nullptr;      // [T][Ptot]
+	double *d_weights_all = nullptr, *d_plk_all = nullptr, *d_total = nullptr;
 	unsigned long schedule_epoch = 0;  // bumped whenever slots are reassigned from scratch
 	bool two_slots = false;            // d_lower / d_lscale hold 2 * core_count slots
 	bool force_root = false;           // the root's outputs (lnL_k, w_k / L_k, lnL) belong to a discarded state
@@ -778,7 +784,7 @@ int launch_upper_walk_params(phyamd_engine *e) {
 	                   e->d_gacc, e->d_props, e->d_weights);
 	double *gsum = e->d_gacc + (size_t)16 * nb * e->C;
 	hipLaunchKernelGGL(k_reduce_rows, dim3(16), dim3(64), 0, e->stream, e->d_gacc, nb * e->C, (const uint8_t *)nullptr, gsum);
-	hipLaunchKernelGGL(k_contract_parameters, dim3(1), dim3(64), 0, e->stream, np, e->d_Bw, gsum, e->d_result + 1 + (size_t)e->N * e->C);
+	hipLaunchKernelGGL(k_contract_parameters, dim3((np + 63) / 64), dim3(64), 0, e->stream, np, e->d_Bw, gsum, e->d_result + 1 + (size_t)e->N * e->C);
 	HIP_TRY(hipGetLastError());
 	e->prof.upper_launches = 1;
 	e->grad_blocks = nb;
@@ -1226,6 +1232,54 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 	return PHYAMD_OK;
 }
 
+__global__ void k_accumulate(int n, const double *__restrict__ src, double *__restrict__ dst) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] += src[i];
+}
+
+// One evaluation = every tile in turn through the same partial storage; the per-tile results ([lnL | gradient rows | parameter
+// sums | root frequency term]: all of them sums over patterns) are added in tile order (fixed: reproducible).
+// mode 0: post-order pass only; 1: + pre-order pass and branch gradient; 2: + substitution-parameter sums
+int run_tiled(phyamd_engine *e, int mode, int flags) {
+	int rc;
+	if ((rc = bind_device(e))) return rc;
+	const int n = mode == 0 ? 1 : 1 + e->N * e->C + (mode == 2 ? e->np + e->S : 0);
+	HIP_TRY(hipMemsetAsync(e->d_total, 0, sizeof(double) * n, e->stream));
+	const uint8_t unknown = e->generic ? (uint8_t)e->S : (uint8_t)0xF;
+	for (int t = 0; t < e->tiles; t++) {
+		const size_t off = (size_t)t * e->P;
+		const size_t w = std::min<size_t>((size_t)e->P, (size_t)e->Ptot - off);
+		HIP_TRY(hipMemcpy2DAsync(e->d_tipmask, (size_t)e->P, e->d_tip_all + off, (size_t)e->Ptot, w, (size_t)e->T, hipMemcpyDeviceToDevice, e->stream));
+		HIP_TRY(hipMemcpyAsync(e->d_weights, e->d_weights_all + off, sizeof(double) * w, hipMemcpyDeviceToDevice, e->stream));
+		if (w < (size_t)e->P) {  // ragged last tile: unknown tips of weight 0 (L = 1, log L = 0, no gradient)
+			HIP_TRY(hipMemset2DAsync(e->d_tipmask + w, (size_t)e->P, unknown, (size_t)e->P - w, (size_t)e->T, e->stream));
+			HIP_TRY(hipMemsetAsync(e->d_weights + w, 0, sizeof(double) * ((size_t)e->P - w), e->stream));
+		}
+		e->all_dirty = true;
+		if ((rc = mode == 0 ? run_lower(e, true) : run_gradient(e, flags, mode == 2))) return rc;
+		hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->d_result, e->d_total);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(e->d_plk_all + off, e->d_plk, sizeof(double) * w, hipMemcpyDeviceToDevice, e->stream));
+	}
+	HIP_TRY(hipMemcpyAsync(e->d_result, e->d_total, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
+	e->tiled_root_term = mode == 2;
+	e->lower_valid = false;  // the resident partials are those of the last tile only
+	e->all_dirty = true;
+	e->upper_valid = false;
+	return PHYAMD_OK;
+}
+
+int eval_lower(phyamd_engine *e) { return e->tiles > 1 ? run_tiled(e, 0, 0) : run_lower(e, true); }
+int eval_gradient(phyamd_engine *e, int flags, bool with_params = false) {
+	return e->tiles > 1 ? run_tiled(e, with_params ? 2 : 1, flags) : run_gradient(e, flags, with_params);
+}
+
+// destination of one tip's pattern codes: the engine's own table, or the all-tiles table
+uint8_t *tip_row(phyamd_engine *e, int tip) { return e->tiles > 1 ? e->d_tip_all + (size_t)tip * e->Ptot : e->d_tipmask + (size_t)tip * e->P; }
+
+#define NOT_TILED(e, what) \
+	if ((e)->tiles > 1) return fail(PHYAMD_EUNSUPPORTED, what " is not available when the patterns are processed in tiles (max_device_bytes)")
+
 void finish_profile(phyamd_engine *e, bool with_upper) {
 	if (!e->profiling || !e->prof_pending) return;
 	e->prof_pending = false;
@@ -1271,9 +1325,33 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	e->cfg = *cfg;
 	e->T = cfg->tip_count;
 	e->N = 2 * e->T - 1;
-	e->P = cfg->pattern_count;
+	e->P = e->Ptot = cfg->pattern_count;
 	e->S = cfg->state_count;
 	e->C = cfg->category_count;
+	if (cfg->max_device_bytes > 0) {
+		// working set of one tile of p patterns: about half of the internal nodes' partials are stored, plus parked uppers
+		// and scratch; resident for all tiles: tip data, weights, per-pattern lnL
+		auto need = [&](double p) {
+			const double pp = e->S == 4 ? p : std::ceil(p / 16.0) * 16.0, npd = (double)e->C * e->S * pp;
+			return 8.0 * (0.5 * (double)(e->N - e->T) * npd + 2.0 * npd) + (double)e->T * p;
+		};
+		const double cap = (double)cfg->max_device_bytes;
+		if (need((double)e->Ptot) > cap) {
+			const double resident = (double)e->T * e->Ptot + 16.0 * e->Ptot;
+			int tiles = 2, per = 0;
+			for (;; tiles++) {
+				per = ((e->Ptot + tiles - 1) / tiles + 255) / 256 * 256;
+				if (need((double)per) + resident <= cap) break;
+				if (per <= 256) {
+					const double least = need(256.0) + resident;
+					delete e;
+					return fail(PHYAMD_ENOMEM, "max_device_bytes %lld is below the smallest tiled working set (%.3g bytes)", (long long)cfg->max_device_bytes, least);
+				}
+			}
+			e->P = per;
+			e->tiles = (e->Ptot + per - 1) / per;
+		}
+	}
 	if (cfg->device >= 0) e->device = cfg->device;
 	else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
 	if (e->device >= ndev) {
@@ -1327,16 +1405,14 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	}
 	e->tip_set.assign(e->T, 0);
 	e->explicit_host.assign(e->N, 0);
-	const size_t np = node_partial_doubles(e);
 	const size_t msz = (size_t)e->N * e->C * e->S * e->S;
-	if (cfg->max_device_bytes > 0) {
-		const double need = 8.0 * (0.5 * (double)(e->N - e->T) * np + 2.0 * np) + (double)e->T * e->P;
-		if (need > (double)cfg->max_device_bytes)
-			return bail(fail(PHYAMD_ENOMEM, "engine needs >= %.3g bytes, max_device_bytes is %lld (pattern tiling is not built in this revision)", need,
-			                 (long long)cfg->max_device_bytes));
-	}
 	int rc;
 	if ((rc = dev_alloc(e, &e->d_tipmask, (size_t)e->T * e->P))) return bail(rc);
+	if (e->tiles > 1) {
+		if ((rc = dev_alloc(e, &e->d_tip_all, (size_t)e->T * e->Ptot)) || (rc = dev_alloc(e, &e->d_weights_all, (size_t)e->Ptot)) ||
+		    (rc = dev_alloc(e, &e->d_plk_all, (size_t)e->Ptot)) || (rc = dev_alloc(e, &e->d_total, (size_t)1 + e->N * e->C + 2 * PHYAMD_MAX_PARAMETERS)))
+			return bail(rc);
+	}
 	if (e->generic && (rc = dev_alloc(e, &e->d_tipsets, (size_t)256))) return bail(rc);
 	// d_lower is sized by the schedule (stored "core" nodes only): ensure_lower_storage
 	if ((rc = dev_alloc(e, &e->d_mats, msz))) return bail(rc);
@@ -1378,7 +1454,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_tipsets, (void *)e->d_pg_nodes, (void *)e->d_pg_core, (void *)e->d_pg_den, (void *)e->d_pg_Gw, (void *)e->d_pg_B, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_tip_all, (void *)e->d_weights_all, (void *)e->d_plk_all, (void *)e->d_total, (void *)e->d_tipsets, (void *)e->d_pg_nodes, (void *)e->d_pg_core, (void *)e->d_pg_den, (void *)e->d_pg_Gw, (void *)e->d_pg_B, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops, (void *)e->d_Qpi})
@@ -1398,12 +1474,12 @@ int phyamd_set_tip_states(phyamd_engine *e, int tip, const uint8_t *states) {
 	if (tip < 0 || tip >= e->T || !states) return fail(PHYAMD_EINVAL, "bad tip %d or null states", tip);
 	int rc;
 	if ((rc = bind_device(e))) return rc;
-	std::vector<uint8_t> mask(e->P);
+	std::vector<uint8_t> mask(e->Ptot);
 	if (e->generic)
-		for (int k = 0; k < e->P; k++) mask[k] = states[k] < e->S ? states[k] : (uint8_t)e->S;  // raw codes; S = unknown
+		for (int k = 0; k < e->Ptot; k++) mask[k] = states[k] < e->S ? states[k] : (uint8_t)e->S;  // raw codes; S = unknown
 	else
-		for (int k = 0; k < e->P; k++) mask[k] = states[k] < 4 ? (uint8_t)(1u << states[k]) : (uint8_t)0xF;  // code >= S: unknown (treelikelihood4.c:946-988)
-	HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
+		for (int k = 0; k < e->Ptot; k++) mask[k] = states[k] < 4 ? (uint8_t)(1u << states[k]) : (uint8_t)0xF;  // code >= S: unknown (treelikelihood4.c:946-988)
+	HIP_TRY(hipMemcpyAsync(tip_row(e, tip), mask.data(), e->Ptot, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->tip_set[tip] = 1;
 	e->all_dirty = true;
@@ -1416,11 +1492,11 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 	if (tip < 0 || tip >= e->T || !partials) return fail(PHYAMD_EINVAL, "bad tip %d or null partials", tip);
 	int rc;
 	if ((rc = bind_device(e))) return rc;
-	std::vector<uint8_t> mask(e->P);
+	std::vector<uint8_t> mask(e->Ptot);
 	if (e->generic) {  // 0/1 vectors: one state, all states, or a set of states (datatype.c:212-240)
 		const int S = e->S;
 		bool grew = false;
-		for (int k = 0; k < e->P; k++) {
+		for (int k = 0; k < e->Ptot; k++) {
 			int ones = 0, last = -1;
 			unsigned long long members = 0;
 			for (int s = 0; s < S; s++) {
@@ -1442,13 +1518,13 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 		}
 		if (grew)
 			HIP_TRY(hipMemcpyAsync(e->d_tipsets, e->tipsets_host.data(), e->tipsets_host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, e->stream));
-		HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
+		HIP_TRY(hipMemcpyAsync(tip_row(e, tip), mask.data(), e->Ptot, hipMemcpyHostToDevice, e->stream));
 		HIP_TRY(hipStreamSynchronize(e->stream));
 		e->tip_set[tip] = 1;
 		e->all_dirty = true;
 		return PHYAMD_OK;
 	}
-	for (int k = 0; k < e->P; k++) {
+	for (int k = 0; k < e->Ptot; k++) {
 		unsigned m = 0;
 		for (int s = 0; s < 4; s++) {
 			const double v = partials[(size_t)k * 4 + s];
@@ -1458,7 +1534,7 @@ int phyamd_set_tip_partials(phyamd_engine *e, int tip, const double *partials) {
 		}
 		mask[k] = (uint8_t)m;
 	}
-	HIP_TRY(hipMemcpyAsync(e->d_tipmask + (size_t)tip * e->P, mask.data(), e->P, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipMemcpyAsync(tip_row(e, tip), mask.data(), e->Ptot, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->tip_set[tip] = 1;
 	e->all_dirty = true;
@@ -1471,7 +1547,7 @@ int phyamd_set_pattern_weights(phyamd_engine *e, const double *weights) {
 	if (!weights) return fail(PHYAMD_EINVAL, "null weights");
 	int rc;
 	if ((rc = bind_device(e))) return rc;
-	HIP_TRY(hipMemcpyAsync(e->d_weights, weights, sizeof(double) * e->P, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipMemcpyAsync(e->tiles > 1 ? e->d_weights_all : e->d_weights, weights, sizeof(double) * e->Ptot, hipMemcpyHostToDevice, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->have_weights = true;
 	e->all_dirty = true;
@@ -1541,6 +1617,7 @@ int phyamd_set_branch_length(phyamd_engine *e, int node, double length) {
 
 int phyamd_store(phyamd_engine *e) {
 	CHECK_ENGINE(e);
+	NOT_TILED(e, "phyamd_store");
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	for (uint8_t x : e->explicit_host)
@@ -1717,7 +1794,7 @@ int phyamd_log_likelihood(phyamd_engine *e, double *lnl) {
 	CHECK_ENGINE(e);
 	if (!lnl) return fail(PHYAMD_EINVAL, "null lnl");
 	int rc;
-	if ((rc = run_lower(e, true))) return rc;
+	if ((rc = eval_lower(e))) return rc;
 	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double), hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	finish_profile(e, false);
@@ -1729,7 +1806,7 @@ int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out) {
 	CHECK_ENGINE(e);
 	if (!device_out) return fail(PHYAMD_EINVAL, "null device_out");
 	int rc;
-	if ((rc = run_gradient(e, flags))) return rc;
+	if ((rc = eval_gradient(e, flags))) return rc;
 	HIP_TRY(hipMemcpyAsync(device_out, e->d_result, sizeof(double) * ((size_t)1 + e->N * e->C), hipMemcpyDeviceToDevice, e->stream));
 	return PHYAMD_OK;
 }
@@ -1738,7 +1815,7 @@ int phyamd_gradient(phyamd_engine *e, int flags, double *lnl, double *cat_gradie
 	CHECK_ENGINE(e);
 	if (!cat_gradient) return fail(PHYAMD_EINVAL, "null cat_gradient");
 	int rc;
-	if ((rc = run_gradient(e, flags))) return rc;
+	if ((rc = eval_gradient(e, flags))) return rc;
 	const size_t n = (size_t)1 + e->N * e->C;
 	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1785,7 +1862,7 @@ int phyamd_parameter_gradient(phyamd_engine *e, int flags, double *lnl, double *
 	CHECK_ENGINE(e);
 	if (!parameter_gradient) return fail(PHYAMD_EINVAL, "null parameter_gradient");
 	int rc;
-	if ((rc = run_gradient(e, flags, true))) return rc;
+	if ((rc = eval_gradient(e, flags, true))) return rc;
 	const size_t ncat = (size_t)e->N * e->C, n = 1 + ncat + e->np;
 	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1802,7 +1879,7 @@ int phyamd_parameter_gradient_device(phyamd_engine *e, int flags, double *device
 	CHECK_ENGINE(e);
 	if (!device_out) return fail(PHYAMD_EINVAL, "null device_out");
 	int rc;
-	if ((rc = run_gradient(e, flags, true))) return rc;
+	if ((rc = eval_gradient(e, flags, true))) return rc;
 	HIP_TRY(hipMemcpyAsync(device_out, e->d_result, sizeof(double) * ((size_t)1 + e->N * e->C + e->np + e->S), hipMemcpyDeviceToDevice, e->stream));
 	return PHYAMD_OK;
 }
@@ -1813,6 +1890,13 @@ int phyamd_root_frequency_term(phyamd_engine *e, double *out) {
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	if ((rc = check_ready(e))) return rc;
+	if (e->tiles > 1) {  // the per-tile terms were summed by the last phyamd_parameter_gradient
+		if (!e->tiled_root_term) return fail(PHYAMD_EINVAL, "with tiled patterns the root frequency term comes with phyamd_parameter_gradient: call that first");
+		HIP_TRY(hipMemcpyAsync(e->h_result, e->d_result + 1 + (size_t)e->N * e->C + e->np, sizeof(double) * e->S, hipMemcpyDeviceToHost, e->stream));
+		HIP_TRY(hipStreamSynchronize(e->stream));
+		std::memcpy(out, e->h_result, sizeof(double) * e->S);
+		return PHYAMD_OK;
+	}
 	if (e->core_index.empty() || e->core_index[e->root] < 0 || !e->d_lower) return fail(PHYAMD_EINVAL, "no evaluation has been run yet");
 	if ((rc = launch_root_frequency_term(e, nullptr))) return rc;
 	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_rf_part + (size_t)((e->P + 255) / 256) * e->S, sizeof(double) * e->S, hipMemcpyDeviceToHost, e->stream));
@@ -1823,6 +1907,7 @@ int phyamd_root_frequency_term(phyamd_engine *e, double *out) {
 
 int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, double *lnl, double *d1, double *d2) {
 	CHECK_ENGINE(e);
+	NOT_TILED(e, "the single-branch evaluation");
 	if (node < 0 || node >= e->N || node == e->root) return fail(PHYAMD_EINVAL, "node %d has no branch", node);
 	if (!e->keep_partials || !e->upper_valid)
 		return fail(PHYAMD_EINVAL, "the single-branch evaluation needs the partials of phyamd_gradient with phyamd_set_keep_partials(1)");
@@ -1889,6 +1974,7 @@ int phyamd_compress_patterns(int device, int32_t taxon_count, int64_t site_count
 
 int phyamd_root_invariant_term(phyamd_engine *e, double *out) {
 	CHECK_ENGINE(e);
+	NOT_TILED(e, "the +I root term");
 	if (!out) return fail(PHYAMD_EINVAL, "null out");
 	if (e->C < 2) return fail(PHYAMD_EINVAL, "the invariant-class term needs at least two categories");
 	int rc;
@@ -1922,13 +2008,14 @@ int phyamd_get_pattern_log_likelihoods(phyamd_engine *e, double *out) {
 	if (!out) return fail(PHYAMD_EINVAL, "null out");
 	int rc;
 	if ((rc = bind_device(e))) return rc;
-	HIP_TRY(hipMemcpyAsync(out, e->d_plk, sizeof(double) * e->P, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipMemcpyAsync(out, e->tiles > 1 ? e->d_plk_all : e->d_plk, sizeof(double) * e->Ptot, hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	return PHYAMD_OK;
 }
 
 int phyamd_get_partials(phyamd_engine *e, int node, int upper, double *out) {
 	CHECK_ENGINE(e);
+	NOT_TILED(e, "reading partials back");
 	if (!out || node < 0 || node >= e->N) return fail(PHYAMD_EINVAL, "bad node %d or null out", node);
 	int rc;
 	if ((rc = bind_device(e))) return rc;
@@ -1990,6 +2077,7 @@ int phyamd_is_rescaling(phyamd_engine *e) {
 
 int phyamd_set_keep_partials(phyamd_engine *e, int on) {
 	CHECK_ENGINE(e);
+	if (on) NOT_TILED(e, "keeping every partial");
 	const bool want = on != 0;
 	if (want == e->keep_partials) return PHYAMD_OK;
 	e->keep_partials = want;
@@ -2013,7 +2101,7 @@ int phyamd_get_profile(phyamd_engine *e, phyamd_profile *out) {
 	if (!out) return fail(PHYAMD_EINVAL, "null out");
 	finish_profile(e, e->prof_with_upper);  // waits for the last evaluation's events if they are still pending
 	e->prof.device_bytes = e->device_bytes;
-	e->prof.tiles = 1;
+	e->prof.tiles = e->tiles;
 	*out = e->prof;
 	return PHYAMD_OK;
 }

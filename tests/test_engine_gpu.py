@@ -562,6 +562,21 @@ def test_parameter_gradient_random_problems(T, P, C, shape, rescale):
         assert np.abs(cg - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
 
 
+@pytest.mark.parametrize("S,count", [(4, 150), (20, 100)])
+def test_parameter_gradient_many_parameters(S, count):
+    """more parameters than states squared (a 12-location symmetric trait model has 66 rates + 12 frequencies): the eigen-basis
+    sums do not depend on the count, only the final contraction does"""
+    pb = random_problem(10, 40, 2, seed=S + count, S=S, gaps=0.05)
+    rng = np.random.default_rng(count)
+    dQ = rng.normal(size=(count, S, S))
+    dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(S)[None]
+    _, og = po.parameter_gradient(pb, dQ)
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        e.set_rate_matrix_derivatives(dQ)
+        _, _, pg = e.parameter_gradient()
+        assert np.abs(pg - og).max() <= 1e-9 * max(1.0, np.abs(og).max())
+
+
 def test_parameter_gradient_argument_checks():
     pb = random_problem(8, 100, 2, seed=3)
     with engine_from_problem(pb) as e:
@@ -573,7 +588,7 @@ def test_parameter_gradient_argument_checks():
         lnl, cg, pg = e.parameter_gradient()
         assert np.all(pg == 0.0)
         with pytest.raises(EngineError):
-            e.set_rate_matrix_derivatives(np.zeros((65, 4, 4)))
+            e.set_rate_matrix_derivatives(np.zeros((2049, 4, 4)))
 
 
 @pytest.mark.parametrize("S,T,P,C,rescale", [(20, 11, 1, 1, 0), (20, 17, 90, 3, 0), (61, 8, 37, 2, 0), (60, 6, 5, 1, 0), (20, 70, 40, 2, 1), (61, 40, 9, 1, 1)])
@@ -695,6 +710,51 @@ def test_single_branch_evaluation(S, T, P, C, fold, rescale):
         e.set_branch_length(0, 0.5)  # the partials no longer belong to the parameters
         with pytest.raises(EngineError):
             e.branch_log_likelihood(0, 0.5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pattern tiling under a device-memory cap (SURVEY 8d "memory feasibility")
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,T,P,C,rescale", [(4, 40, 3000, 4, RESCALE_NEVER), (4, 30, 1000, 2, RESCALE_ALWAYS), (20, 12, 1500, 2, RESCALE_NEVER),
+                                             (61, 8, 700, 1, RESCALE_NEVER)])
+def test_pattern_tiling_under_a_memory_cap(S, T, P, C, rescale):
+    """max_device_bytes below the untiled working set: the engine walks the patterns in tiles through one set of partial
+    arrays and adds the per-tile sums in tile order.  lnL, per-pattern lnL, the gradient and the substitution-parameter sums
+    equal the untiled engine's (ragged last tile included); calls that need resident partials are refused."""
+    forced = rescale == RESCALE_ALWAYS
+    pb = random_problem(T, P, C, seed=4000 + S + T, S=S, gaps=0.04, bl=(0.3, 0.9) if forced else (0.01, 0.1), rescale=1 if forced else 0)
+    rng = np.random.default_rng(S)
+    dQ = rng.normal(size=(3, S, S))
+    dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(S)[None]
+    per_pattern = 8.0 * C * S * (0.5 * (T - 1) + 2.0) + T  # the engine's own estimate of its working set
+    cap = int(per_pattern * 600 + T * P + 16 * P)          # room for ~600 patterns at a time: tiles of 512
+    with engine_from_problem(pb, rescale=rescale) as whole, engine_from_problem(pb, rescale=rescale, max_device_bytes=cap) as e:
+        tiles = e.profile()["tiles"]
+        assert tiles == -(-P // 512) and whole.profile()["tiles"] == 1
+        assert e.profile()["device_bytes"] < whole.profile()["device_bytes"]
+        lnl = e.log_likelihood()
+        ref = whole.log_likelihood()
+        assert abs(lnl - ref) <= 1e-12 * abs(ref)
+        np.testing.assert_allclose(e.pattern_log_likelihoods(), whole.pattern_log_likelihoods(), rtol=1e-13, atol=1e-13)
+        l2, cg = e.gradient()
+        l3, cg_ref = whole.gradient()
+        assert abs(l2 - l3) <= 1e-12 * abs(l3)
+        assert np.abs(cg - cg_ref).max() <= 1e-10 * max(1.0, np.abs(cg_ref).max())
+        e.set_rate_matrix_derivatives(dQ)
+        whole.set_rate_matrix_derivatives(dQ)
+        if S == 4 or not forced:
+            _, _, pg = e.parameter_gradient()
+            _, _, pg_ref = whole.parameter_gradient()
+            assert np.abs(pg - pg_ref).max() <= 1e-10 * max(1.0, np.abs(pg_ref).max())
+            np.testing.assert_allclose(e.root_frequency_term(), whole.root_frequency_term(), rtol=1e-11)
+        e.set_branch_length(0, 0.2)  # a changed branch: every tile is recomputed
+        whole.set_branch_length(0, 0.2)
+        assert abs(e.log_likelihood() - whole.log_likelihood()) <= 1e-12 * abs(ref)
+        for call in (lambda: e.partials(T), lambda: e.set_keep_partials(True), lambda: e.store(), lambda: e.branch_log_likelihood(0, 0.1)):
+            with pytest.raises(EngineError):
+                call()
+    with pytest.raises(EngineError):
+        Engine(T, P, S, C, max_device_bytes=1000)  # below the smallest tile
 
 
 # ---------------------------------------------------------------------------------------------------------
