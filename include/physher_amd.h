@@ -153,6 +153,9 @@ int phyamd_gradient(phyamd_engine *e, int flags, double *lnl, double *cat_gradie
  * branch_gradient[node] = sum_c g[node][c] w_c r_c  (r_c WITHOUT mu: pass them here).  [2T-1]. */
 int phyamd_branch_gradient(phyamd_engine *e, int flags, const double *rates_without_mu /* [C] or NULL */, double *lnl,
                            double *branch_gradient);
+/* lnL alone, left on the device (device_out[0]) on the engine's stream: the post-order pass without a host round trip
+ * (with PHYAMD_RESCALE_AUTO an unscaled engine still reads lnL back once to test for +-inf, treelikelihood.c:1496-1519). */
+int phyamd_log_likelihood_device(phyamd_engine *e, double *device_out);
 /* Device-resident result for multi-GPU sharding: writes [lnL, g[0][0..C-1], g[1][..], ...]
  * (1 + (2T-1)*C doubles) to `device_out` on the engine's stream, no host synchronisation. */
 int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out);

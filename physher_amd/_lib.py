@@ -58,6 +58,7 @@ SYMBOLS = [
     ("phyamd_gradient", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), _P]),
     ("phyamd_branch_gradient", C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), _P]),
     ("phyamd_gradient_device", C.c_int, [_P, C.c_int, _P]),
+    ("phyamd_log_likelihood_device", C.c_int, [_P, _P]),
     ("phyamd_root_invariant_term", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("phyamd_set_rate_matrix_derivatives", C.c_int, [_P, C.c_int, _P]),
     ("phyamd_parameter_gradient", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), _P, _P]),

@@ -1802,6 +1802,15 @@ int phyamd_log_likelihood(phyamd_engine *e, double *lnl) {
 	return PHYAMD_OK;
 }
 
+int phyamd_log_likelihood_device(phyamd_engine *e, double *device_out) {
+	CHECK_ENGINE(e);
+	if (!device_out) return fail(PHYAMD_EINVAL, "null device_out");
+	int rc;
+	if ((rc = eval_lower(e))) return rc;
+	HIP_TRY(hipMemcpyAsync(device_out, e->d_result, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+	return PHYAMD_OK;
+}
+
 int phyamd_gradient_device(phyamd_engine *e, int flags, double *device_out) {
 	CHECK_ENGINE(e);
 	if (!device_out) return fail(PHYAMD_EINVAL, "null device_out");

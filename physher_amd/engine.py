@@ -132,6 +132,10 @@ class Engine:
         self._check(self._lib.phyamd_branch_gradient(self._h, flags, None if r is None else _ptr(r), C.byref(v), _ptr(g)))
         return v.value, g
 
+    def log_likelihood_device(self, device_ptr):
+        """post-order pass only; lnL -> device_ptr[0] on the engine's stream"""
+        self._check(self._lib.phyamd_log_likelihood_device(self._h, C.c_void_p(device_ptr)))
+
     def gradient_device(self, device_ptr, flags=0):
         self._check(self._lib.phyamd_gradient_device(self._h, flags, C.c_void_p(device_ptr)))
 
