@@ -26,6 +26,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.phyamd_abi_version() == _lib.ABI_VERSION
 
 
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: the header compiles as C99 (no C++ types, no torch types) and a C caller links against the library"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    src = tmp_path / "caller.c"
+    src.write_text('#include "physher_amd.h"\n#include <stdio.h>\n'
+                   'int main(void) { phyamd_config cfg = {0}; phyamd_engine *e = 0; cfg.tip_count = 1; '
+                   'int rc = phyamd_create(&cfg, &e); printf("%d %d %s\\n", phyamd_abi_version(), rc, phyamd_last_error()); return rc == PHYAMD_EINVAL ? 0 : 1; }\n')
+    exe = tmp_path / "caller"
+    lib_dir = os.path.join(ROOT, "physher_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", str(exe), str(src),
+                           "-L" + lib_dir, "-lphysher_amd", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr  # tip_count 1 is refused before any device is touched
+    assert "tip_count" in out.stdout
+
+
 def test_null_and_bad_arguments_are_reported_not_crashed():
     from physher_amd import _lib
     lib = _lib.load()
