@@ -165,6 +165,45 @@ def run_fluA_hky_g4():
     print(f"fluA_hky_g4_time: lnL={data['lnl_jacobian0']!r}, gradient blocks={len(data['gradient_all_time'])} flags={data['gradient_all_time_flags']}")
 
 
+def run_fluA_discrete_clock():
+    """fluA under HKY + G4 with one clock rate per branch (the reference's "discrete" branch model = phycpp's
+    SimpleClockModelInterface, physher.cpp:188-217): pins the per-branch clock block of the time-tree gradient."""
+    src = os.path.join(HERE, "fluA_jc69_time")
+    d = os.path.join(HERE, "fluA_hky_g4_branch_rates")
+    os.makedirs(d, exist_ok=True)
+    shutil.copyfile(os.path.join(src, "fluA.fa"), os.path.join(d, "fluA.fa"))
+    with open(os.path.join(src, "jc69-time.json")) as f:
+        js = json.load(f)
+    model = js["model"]
+    model["sitemodel"]["substitutionmodel"] = {
+        "id": "sm", "type": "substitutionmodel", "model": "hky", "datatype": "nucleotide",
+        "frequencies": {"id": "freqs", "type": "Simplex", "values": [0.33, 0.19, 0.23, 0.25]},
+        "rates": {"kappa": {"id": "kappa", "type": "parameter", "value": 3.0, "lower": 0, "upper": "infinity"}},
+    }
+    model["sitemodel"]["distribution"] = {
+        "distribution": "gamma", "categories": 4,
+        "parameters": {"alpha": {"id": "alpha", "type": "parameter", "value": 0.6, "lower": 0, "upper": "infinity"}},
+    }
+    n_branches = 2 * 69 - 2
+    rng = np.random.default_rng(31)
+    rates = np.round(rng.uniform(0.0008, 0.0025, size=n_branches), 7)
+    model["branchmodel"] = {"id": "bm", "type": "branchmodel", "model": "discrete", "tree": "&tree",
+                            "parameters": {"id": "clock_rates", "type": "parameter", "dimension": n_branches,
+                                           "values": [float(x) for x in rates], "lower": 0}}
+    with open(os.path.join(d, "hky-g4-branch-rates.json"), "w") as f:
+        json.dump({"model": model}, f, indent=1)
+    out = os.path.join(d, "expected.json")
+    subprocess.check_call([DRIVER, "json", "hky-g4-branch-rates.json", out], cwd=d, stdout=subprocess.DEVNULL)
+    with open(out) as f:
+        data = json.load(f)
+    os.remove(out)
+    for k in SLIM_DROP:
+        data.pop(k, None)
+    with gzip.GzipFile(out + ".gz", "w", mtime=0) as f:
+        f.write(json.dumps(data, separators=(",", ":")).encode())
+    print(f"fluA_hky_g4_branch_rates: lnL={data['lnl_jacobian0']!r}, gradient entries={len(data['gradient_all_time'])} flags={data['gradient_all_time_flags']}")
+
+
 ATTR_CASES = [
     # discrete traits (one attribute per taxon, general data type): the wrapper's second constructor (physher.cpp:594-629)
     ("trait_k5_g3_t14", dict(T=14, K=5, seed=21, categories=3, alpha=0.8, n_rates=3, unknown=(3,), ambiguities={})),
@@ -252,6 +291,8 @@ if __name__ == "__main__":
         run_fluA()
     if not only or "fluA_hky_g4_time" in only:
         run_fluA_hky_g4()
+    if not only or "fluA_hky_g4_branch_rates" in only:
+        run_fluA_discrete_clock()
     for name, opts in ATTR_CASES:
         if not only or name in only:
             run_attr_case(name, opts)

@@ -440,3 +440,48 @@ def test_fluA_time_tree_hky_gamma_all_gradient_blocks():
     tlk2.set_reference_compatibility(True)  # tree + clock only: the reference folds the root frequencies (inexact for this pi)
     ref1 = np.array(gold["gradient_tree_clock_jacobian1"])
     assert np.abs(tlk2.gradient() - ref1).max() <= 1e-9 * np.abs(ref1).max()
+
+
+def test_fluA_time_tree_per_branch_clock_rates():
+    """One clock rate per branch (the reference's "discrete" branch model = SimpleClockModelInterface, physher.cpp:188-217) on
+    the fluA time tree under HKY + G4; fixture from the compiled reference (make_golden.py::run_fluA_discrete_clock).  The
+    reference numbers its rates by node id, the wrapper by taxon index (tips) / class id + T (internal nodes)."""
+    from physher_amd import _phycpp_amd as pc
+    F = pc.TreeLikelihoodGradientFlags
+    d = os.path.join(GOLDEN, "fluA_hky_g4_branch_rates")
+    with open(os.path.join(d, "hky-g4-branch-rates.json")) as f:
+        js = json.load(f)["model"]
+    gold = load("fluA_hky_g4_branch_rates")
+    names, seqs = read_fasta(os.path.join(d, "fluA.fa"))
+    T = len(names)
+    dates = [float(js["tree"]["dates"][t]) for t in names]
+    ref_rates = js["branchmodel"]["parameters"]["values"]
+    index_of = {}  # reference node id -> the wrapper's rate index
+    for nd in gold["nodes"]:
+        if nd["id"] != gold["root"]:
+            index_of[nd["id"]] = names.index(nd["name"]) if nd["left"] < 0 else nd["class_id"] + T
+    assert sorted(index_of.values()) == list(range(2 * T - 2)) and sorted(index_of) == list(range(2 * T - 2))
+    rates = np.zeros(2 * T - 2)
+    for node, idx in index_of.items():
+        rates[idx] = ref_rates[node]
+    tree = pc.ReparameterizedTimeTreeModelInterface(js["tree"]["newick"], names, dates, pc.TreeTransformFlags.RATIO)
+    clock = pc.SimpleClockModelInterface(list(rates), tree)
+    sm = js["sitemodel"]["substitutionmodel"]
+    subst = pc.HKYInterface(sm["rates"]["kappa"]["value"], sm["frequencies"]["values"])
+    site = pc.GammaSiteModelInterface(js["sitemodel"]["distribution"]["parameters"]["alpha"]["value"], 4, None, None)
+    tlk = pc.TreeLikelihoodInterface(list(zip(names, seqs)), tree, subst, site, clock, use_tip_states=True, include_jacobian=False)
+    lnl = tlk.log_likelihood()
+    assert abs(lnl - gold["lnl_jacobian0"]) <= 1e-10 * abs(lnl)
+    ref = np.array(gold["gradient_all_time"])
+    n_clock = 2 * T - 2
+    assert len(ref) == (T - 1) + 1 + n_clock + 5
+    tlk.request_gradient([F.TREE_HEIGHT, F.SITE_MODEL, F.BRANCH_MODEL, F.SUBSTITUTION_MODEL])
+    assert tlk.gradient_length == len(ref)
+    g = tlk.gradient()
+    assert np.abs(g[:T - 1] - ref[:T - 1]).max() <= 1e-9 * np.abs(ref[:T - 1]).max()          # ratios, root height
+    assert abs(g[T - 1] - ref[T - 1]) <= 2e-7 * max(1.0, abs(ref[T - 1]))                       # gamma shape
+    gc, rc = g[T: T + n_clock], ref[T: T + n_clock]
+    scale = np.abs(rc).max()
+    for node, idx in index_of.items():                                                          # one rate per branch
+        assert abs(gc[idx] - rc[node]) <= 1e-9 * scale, (node, idx, gc[idx], rc[node])
+    np.testing.assert_allclose(g[T + n_clock:], ref[T + n_clock:], rtol=2e-8, atol=1e-7)         # kappa, frequencies
