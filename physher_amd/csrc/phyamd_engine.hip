@@ -160,6 +160,8 @@ struct phyamd_engine {
 	NodeOp *d_walk_lower_ops = nullptr, *d_walk_upper_ops = nullptr;
 	int walk_upper_slots = 0;
 	double *d_Lc = nullptr;  // [C][P] per-category site likelihoods at the root (generic)
+	double *d_imgs = nullptr;  // generic: MFMA fragment images of P(t) per (node, category), then of Q (k_matrix_images)
+	bool qimg_dirty = true;
 	double *d_inv_part = nullptr;  // partial sums of k_root_invariant_term
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -585,7 +587,27 @@ int check_ready(phyamd_engine *e) {
 	return PHYAMD_OK;
 }
 
+size_t gen_image_doubles(const phyamd_engine *e) {
+	return e->S == 20 ? MatImage<2, 5>::SIZE : e->S == 60 ? MatImage<4, 15>::SIZE : MatImage<4, 16>::SIZE;
+}
+
+template <int RT, int KT>
+void launch_matrix_images(phyamd_engine *e, int count, const double *src, double *dst) {
+	hipLaunchKernelGGL((k_matrix_images<RT, KT>), dim3(count), dim3(256), 0, e->stream, e->S, src, dst);
+}
+
+void build_matrix_images(phyamd_engine *e, int count, const double *src, double *dst) {
+	if (e->S == 20) launch_matrix_images<2, 5>(e, count, src, dst);
+	else if (e->S == 60) launch_matrix_images<4, 15>(e, count, src, dst);
+	else launch_matrix_images<4, 16>(e, count, src, dst);
+}
+
 int update_matrices(phyamd_engine *e) {
+	if (e->generic && e->qimg_dirty && e->have_Q) {  // the rate matrix's image sits behind the per-(node, category) ones
+		build_matrix_images(e, 1, e->d_Q, e->d_imgs + (size_t)e->N * e->C * gen_image_doubles(e));
+		HIP_TRY(hipGetLastError());
+		e->qimg_dirty = false;
+	}
 	if (!e->matrices_dirty) return PHYAMD_OK;
 	if (e->have_eigen) {
 		const size_t total = (size_t)e->N * e->C * e->S * e->S;
@@ -597,6 +619,9 @@ int update_matrices(phyamd_engine *e) {
 	if (!e->generic) {  // explicit matrices included: the tables are built from whatever d_mats holds
 		const int n = e->T * e->C * 64;
 		hipLaunchKernelGGL(k_tip_tables, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, e->C, e->d_mats, e->d_tiptab);
+		HIP_TRY(hipGetLastError());
+	} else {
+		build_matrix_images(e, e->N * e->C, e->d_mats, e->d_imgs);
 		HIP_TRY(hipGetLastError());
 	}
 	e->matrices_dirty = false;
@@ -862,10 +887,10 @@ int launch_lower_gen(phyamd_engine *e) {
 		const bool is_root = lv == levels - 1;
 		if (is_root)
 			hipLaunchKernelGGL((k_lower_gen<RT, KT, true, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->act_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
+			                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_imgs, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
 		else
 			hipLaunchKernelGGL((k_lower_gen<RT, KT, false, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->act_lower_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-			                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_mats, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
+			                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_imgs, e->d_freqs, e->d_props, e->d_Lc, e->d_gen_scratch);
 		if (SCALE)
 			hipLaunchKernelGGL(k_scale_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->act_lower_ops + off, e->P, e->Pp, e->S, e->C, e->d_lower, e->d_gen_scratch,
 			                   e->d_lscale, is_root ? e->d_Lc : (double *)nullptr);
@@ -892,7 +917,8 @@ int launch_upper_gen_v(phyamd_engine *e, bool compat) {
 		dim3 grid(e->nblk, cnt, e->C);
 		if (SCALE) mxu = e->d_gen_scratch + (size_t)cnt * 3 * e->C * e->P;
 		hipLaunchKernelGGL((k_upper_gen<RT, KT, FOLD, SCALE>), grid, dim3(GenGeo<RT>::WAVES * 64), lds, e->stream, e->d_upper_ops + off, e->T, e->P, e->Pp, e->S, e->C,
-		                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_upper, e->d_mats, e->d_Q, e->d_freqs, e->d_wl, e->d_gpart, e->nblk, nd, mxu);
+		                   e->d_tipmask, e->d_tipsets, e->d_lower, e->d_upper, e->d_imgs, e->d_imgs + (size_t)e->N * e->C * MatImage<RT, KT>::SIZE, e->d_freqs, e->d_wl,
+		                   e->d_gpart, e->nblk, nd, mxu);
 		if (SCALE) {
 			hipLaunchKernelGGL(k_scale_upper_gen, dim3(pblocks, cnt), dim3(256), 0, e->stream, e->d_upper_ops + off, e->P, e->Pp, e->S, e->C, e->d_upper, mxu);
 			const int ppb = GenGeo<RT>::PATTERNS_PER_BLOCK;
@@ -1414,6 +1440,7 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 			return bail(rc);
 	}
 	if (e->generic && (rc = dev_alloc(e, &e->d_tipsets, (size_t)256))) return bail(rc);
+	if (e->generic && (rc = dev_alloc(e, &e->d_imgs, ((size_t)e->N * e->C + 1) * gen_image_doubles(e)))) return bail(rc);
 	// d_lower is sized by the schedule (stored "core" nodes only): ensure_lower_storage
 	if ((rc = dev_alloc(e, &e->d_mats, msz))) return bail(rc);
 	if ((rc = dev_alloc(e, &e->d_dmats, msz))) return bail(rc);
@@ -1454,7 +1481,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_tipmask, (void *)e->d_tip_all, (void *)e->d_weights_all, (void *)e->d_plk_all, (void *)e->d_total, (void *)e->d_tipsets, (void *)e->d_pg_nodes, (void *)e->d_pg_core, (void *)e->d_pg_den, (void *)e->d_pg_Gw, (void *)e->d_pg_B, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_imgs, (void *)e->d_tipmask, (void *)e->d_tip_all, (void *)e->d_weights_all, (void *)e->d_plk_all, (void *)e->d_total, (void *)e->d_tipsets, (void *)e->d_pg_nodes, (void *)e->d_pg_core, (void *)e->d_pg_den, (void *)e->d_pg_Gw, (void *)e->d_pg_B, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops, (void *)e->d_Qpi})
@@ -1721,6 +1748,7 @@ int phyamd_set_eigen(phyamd_engine *e, const double *eval, const double *evec, c
 	e->Q_host = Q;
 	e->qpi_dirty = true;
 	e->have_Q = true;
+	e->qimg_dirty = true;
 	std::fill(e->explicit_host.begin(), e->explicit_host.end(), 0);
 	HIP_TRY(hipMemsetAsync(e->d_explicit, 0, e->N, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1787,6 +1815,7 @@ int phyamd_set_rate_matrix(phyamd_engine *e, const double *Q) {
 	e->Q_host.assign(Q, Q + (size_t)e->S * e->S);
 	e->qpi_dirty = true;
 	e->have_Q = true;
+	e->qimg_dirty = true;
 	return PHYAMD_OK;
 }
 
