@@ -215,7 +215,7 @@ struct phyamd_engine {
 	double *d_ppart = nullptr;       // [np][upper ops][nblk] per-workgroup parameter sums, then [np][upper ops]
 	double *d_Bw = nullptr;          // tree-walk G2: [np][16] U^-1 dQ U
 	double *d_pbuf = nullptr;        // tree-walk G2: [UTpi 16 | Uinv 16 | utab 64]
-	double *d_Fw = nullptr;          // tree-walk G2: [N][C][16] w_c F_ab(t_n r_c)
+	double *d_Fw = nullptr;          // tree-walk G2: [N][C][20] w_c F_ab(t_n r_c), l_a e^{l_a t_n r_c}
 	double *d_gacc = nullptr;        // tree-walk G2: [16][slabs * C] per-wave eigen-basis sums, then [16] totals
 	double *d_branch = nullptr;      // phyamd_branch_log_likelihood: [C][3][16] matrices | [3][blocks] partial sums | [3]
 	bool upper_fold = false;         // the stored uppers carry the root frequencies (last gradient call used FOLD)
@@ -765,7 +765,7 @@ int launch_upper_walk_params(phyamd_engine *e) {
 		e->np_alloc_B = np;
 	}
 	if (!e->d_pbuf && (rc = dev_alloc(e, &e->d_pbuf, 96))) return rc;
-	if (!e->d_Fw && (rc = dev_alloc(e, &e->d_Fw, (size_t)e->N * e->C * 16))) return rc;
+	if (!e->d_Fw && (rc = dev_alloc(e, &e->d_Fw, (size_t)e->N * e->C * 20))) return rc;
 	if (!e->d_gacc && (rc = dev_alloc(e, &e->d_gacc, (size_t)16 * nb * e->C + 16))) return rc;
 	{
 		const double *evec = e->model.data() + S, *ivec = e->model.data() + S + S * S;
@@ -801,7 +801,7 @@ int launch_upper_walk_params(phyamd_engine *e) {
 		HIP_TRY(hipMemcpyAsync(e->d_pbuf, pb.data(), sizeof(double) * pb.size(), hipMemcpyHostToDevice, e->stream));
 		HIP_TRY(hipStreamSynchronize(e->stream));
 	}
-	const int nf = e->N * e->C * 16;
+	const int nf = e->N * e->C * 20;
 	hipLaunchKernelGGL(k_eigen_weights, dim3((nf + 255) / 256), dim3(256), 0, e->stream, e->C, e->N, e->d_model, e->d_rates, e->d_props, e->d_lengths, e->d_explicit,
 	                   e->root, e->d_Fw);
 	hipLaunchKernelGGL((k_upper4_walk<WAVES, false, true, SCALE, false>), dim3(e->nblk_walk_upper), block_dims(e), lds, e->stream, e->d_walk_upper_ops, ops, e->T,
@@ -1218,13 +1218,15 @@ int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 		if ((rc = rebuild_schedule(e))) return rc;
 		if ((rc = run_lower(e, true))) return rc;
 	}
-	if (with_params && !e->generic && !(e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on)))
-		e->level_upper_needed = true;
+	bool any_explicit = false;  // explicit matrices have no eigen system: the tree-walk's eigen-basis branch term does not cover them
+	for (uint8_t x : e->explicit_host) any_explicit |= x != 0;
+	const bool walk_params = with_params && !any_explicit && !e->generic && e->walking && e->walk_upper_on && e->walk_params_on &&
+	                         !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on);
+	if (with_params && !e->generic && !walk_params) e->level_upper_needed = true;
 	if ((rc = ensure_upper_storage(e))) return rc;
 	if (!e->have_Q) return fail(PHYAMD_EINVAL, "the gradient needs the rate matrix: phyamd_set_eigen or phyamd_set_rate_matrix");
 	e->grad_blocks = e->nblk;
 	// (the compat flag changes only the branch terms; parameter sums always use the mixture denominator: level kernels then)
-	const bool walk_params = with_params && !e->generic && e->walking && e->walk_upper_on && e->walk_params_on && !((flags & PHYAMD_GRAD_COMPAT_SCALED) && e->scaling_on);
 	if (walk_params) {
 		const int waves = e->C * e->G;
 		if (e->scaling_on)
