@@ -234,6 +234,69 @@ def test_full_size_properties():
         e.set_branch_lengths(tree.length)
 
 
+def test_headline_size_properties():
+    """BASELINE's metric shape itself -- 1000 taxa x 1e6 patterns x 4 states x 4 categories on one GPU (48.7 GB resident):
+    bitwise reproducibility, sum of the per-pattern lnL, additivity over two half-size shards (what multi-GPU sharding
+    relies on), equality with the tiled engine under a 16 GB cap, and the gradient against a central difference of lnL."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from physher_amd import synth
+    T, P, C = 1000, 1_000_000, 4
+    rng = np.random.default_rng(1)
+    tree = synth.random_tree(T, rng)
+    states = bench.evolve_on_device(tree, P, 5, torch.device("cuda", 0), 4).cpu().numpy()
+    ev, U, Ui = bench.gtr_eigen()
+    rates = np.array(bench.GAMMA4_RATES_05)
+    rates /= rates.mean()
+    props = np.full(C, 0.25)
+    weights = rng.integers(1, 4, size=P).astype(np.float64)
+
+    def make(lo, hi, **kw):
+        e = Engine(T, hi - lo, 4, C, rescale=RESCALE_AUTO, **kw)
+        e.set_topology(tree.left, tree.right, tree.root)
+        e.set_branch_lengths(tree.length)
+        e.set_eigen(ev, U, Ui)
+        e.set_frequencies(np.array(bench.GTR_FREQS))
+        e.set_category_rates(rates, props)
+        e.set_pattern_weights(weights[lo:hi])
+        for t in range(T):
+            e.set_tip_states(t, np.ascontiguousarray(states[t, lo:hi]))
+        return e
+
+    with make(0, P) as e:
+        assert 40e9 < e.profile()["device_bytes"] < 60e9
+        lnl, cg = e.gradient()
+        lnl2, cg2 = e.gradient()
+        assert np.isfinite(lnl) and lnl == lnl2 and np.array_equal(cg, cg2)
+        assert not e.rescaling
+        assert abs(np.dot(e.pattern_log_likelihoods(), weights) - lnl) <= 1e-11 * abs(lnl)
+        bg = po.branch_gradient_from_cat(cg, rates, props)
+        n = int(tree.left[tree.root])
+        h = 1e-6
+        bl = tree.length.copy()
+        bl[n] += h
+        e.set_branch_lengths(bl)
+        up = e.log_likelihood()
+        bl[n] -= 2 * h
+        e.set_branch_lengths(bl)
+        dn = e.log_likelihood()
+        assert abs((up - dn) / (2 * h) - bg[n]) <= 1e-4 * max(1.0, abs(bg[n]))
+    halves = []
+    for lo, hi in ((0, P // 2), (P // 2, P)):
+        with make(lo, hi) as h_:
+            halves.append(h_.gradient())
+    assert abs(halves[0][0] + halves[1][0] - lnl) <= 1e-12 * abs(lnl)
+    assert np.abs(halves[0][1] + halves[1][1] - cg).max() <= 1e-11 * np.abs(cg).max()
+    with make(0, P, max_device_bytes=16_000_000_000) as tiled:
+        assert tiled.profile()["tiles"] >= 4 and tiled.profile()["device_bytes"] < 16e9
+        lnl_t, cg_t = tiled.gradient()
+        assert abs(lnl_t - lnl) <= 1e-12 * abs(lnl)
+        assert np.abs(cg_t - cg).max() <= 1e-11 * np.abs(cg).max()
+
+
 def test_fusion_switch_and_memory():
     """PHYAMD_FUSE=0 gives the unfused schedule; results agree and the fused engine stores about half the arrays."""
     import os
