@@ -238,20 +238,15 @@ def test_headline_size_properties():
     """BASELINE's metric shape itself -- 1000 taxa x 1e6 patterns x 4 states x 4 categories on one GPU (48.7 GB resident):
     bitwise reproducibility, sum of the per-pattern lnL, additivity over two half-size shards (what multi-GPU sharding
     relies on), equality with the tiled engine under a 16 GB cap, and the gradient against a central difference of lnL."""
-    import os
-    import sys
-    import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
     from physher_amd import synth
     T, P, C = 1000, 1_000_000, 4
     rng = np.random.default_rng(1)
     tree = synth.random_tree(T, rng)
-    states = bench.evolve_on_device(tree, P, 5, torch.device("cuda", 0), 4).cpu().numpy()
-    ev, U, Ui = bench.gtr_eigen()
-    rates = np.array(bench.GAMMA4_RATES_05)
-    rates /= rates.mean()
-    props = np.full(C, 0.25)
+    # 1e5 evolved columns repeated ten times with independent weights: the kernels see 1e6 patterns either way, and host-side
+    # generation stays at seconds (torch is not used here: its bundled HIP runtime cannot initialise after the engine's)
+    states = np.tile(synth.evolve(tree, P // 10, 4, rng), (1, 10))
+    model = random_problem(T, 8, C, seed=5)  # borrow a GTR-like model and gamma rates
+    ev, U, Ui, freqs, rates, props = model.eval, model.evec, model.ivec, model.freqs, model.cat_rates, model.cat_props
     weights = rng.integers(1, 4, size=P).astype(np.float64)
 
     def make(lo, hi, **kw):
@@ -259,7 +254,7 @@ def test_headline_size_properties():
         e.set_topology(tree.left, tree.right, tree.root)
         e.set_branch_lengths(tree.length)
         e.set_eigen(ev, U, Ui)
-        e.set_frequencies(np.array(bench.GTR_FREQS))
+        e.set_frequencies(freqs)
         e.set_category_rates(rates, props)
         e.set_pattern_weights(weights[lo:hi])
         for t in range(T):
