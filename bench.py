@@ -363,6 +363,9 @@ def main():
                          "hbm_measured": None if traffic is None or prof["upper_ms"] <= 0 else
                                          {"GB/s": traffic * launches / (prof["upper_ms"] * 1e-3) / 1e9,
                                           "frac_of_peak": traffic * launches / (prof["upper_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "note": "achieved = the reference's three-pass algorithmic bytes of the pre-order + gradient passes (SURVEY 8d) / kernel time; "
+                                 "the fused kernels move about a tenth of them (traffic = PMC bytes per launch), so frac exceeds 1; "
+                                 "hbm_measured is the real HBM rate of the same launches",
                          "algorithmic_bytes_per_launch": upper_b / launches, "launches_per_eval": launches,
                          "avg_launch_ms": prof["upper_ms"] / launches,
                          "lower_kernel": {"kernel": f"k_lower{kern}" if p["lower_launches"] == 1 or S != 4 else "k_lower4", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
