@@ -1,0 +1,20 @@
+#!/bin/bash
+# profiles/collect_generic.sh TAG -- rocprofv3 kernel stats of the 20- and 61-state workloads (bench.py --config cfg3 / cfg4),
+# run on the GPU box from the repo root; summaries land in gpurun_out/prof_TAG/ (copy what is to be judged into profiles/).
+set -eo pipefail
+TAG=${1:?tag}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for cfg in cfg3 cfg4; do
+	rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$cfg -o kt -- python3 $ROOT/bench.py --no-cpu-baseline --config $cfg --steps 10 --warmup 2 \
+		> "$OUT/${TAG}_${cfg}_bench_under_rocprof.json" 2> "$OUT/$cfg.err"
+	f=$(find /tmp/prof_$cfg -name 'kt_kernel_stats.csv' | head -1)
+	head -1 "$f" > "$OUT/${TAG}_${cfg}_kernel_stats.csv"
+	grep -E 'k_lower_gen|k_upper_gen|k_matrix_images|k_transition|k_root|k_reduce_rows|k_scale' "$f" >> "$OUT/${TAG}_${cfg}_kernel_stats.csv" || true
+	echo "$cfg done" >&2
+done
+cd "$ROOT"
+for cfg in cfg3 cfg4; do python3 bench.py --no-cpu-baseline --config $cfg --steps 10 --warmup 2 > "$OUT/${TAG}_${cfg}_bench.json" 2>> "$OUT/$cfg.err"; done
+ls "$OUT" >&2
