@@ -260,7 +260,11 @@ def main():
     else:
         freqs, ev, U, Ui = reversible_eigen(S, args.seed)
 
-    stream = torch.cuda.current_stream(device)
+    # ONE stream for the engine's kernels and for everything torch does with their output (device-to-host copies, the
+    # RCCL all-reduce): torch's default stream has handle 0, which the engine would take as "create your own stream", and a
+    # stream of its own is not ordered with torch's work -- the reduction could read the result vector before it is written
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
     eng = Engine(T, Pl, S, C, device=local_rank, rescale={"auto": RESCALE_AUTO, "always": RESCALE_ALWAYS, "never": RESCALE_NEVER}[args.rescale],
                  stream=stream.cuda_stream, max_device_bytes=int(args.max_device_gb * 1e9))
     eng.set_topology(tree.left, tree.right, tree.root)

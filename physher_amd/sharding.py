@@ -48,6 +48,9 @@ class ShardedLikelihood:
 
     evaluate_shard(out) must write this shard's [lnL, cat-gradient] into `out` (a torch tensor); on GPUs that is
     Engine.gradient_device(out.data_ptr()) -- the HIP kernels -- and in the CPU tests a stand-in.
+    The engine writes `out` asynchronously on ITS stream: create it with stream = a non-default torch stream that is also
+    torch's current stream (torch.cuda.set_stream), so that the all-reduce and the host copy below are ordered behind the
+    kernels.  (Handle 0, torch's default stream, means "engine-owned stream" to phyamd_create and is NOT ordered with torch.)
     """
 
     def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False, tail=0):

@@ -42,3 +42,20 @@ def test_bench_secondary_modes():
     assert _run(["--no-cpu-baseline", "--subst-gradient"])["value"] > 0
     d = _run(["--no-cpu-baseline", "--rescale", "always"])
     assert d["config"]["rescaling"] is True
+
+
+def test_bench_two_rank_launch_path():
+    """the driver's N > 1 launch line (torch.distributed.run, one rank per GPU) rehearsed on one GPU: both ranks use cuda:0
+    and a gloo group (PHYAMD_BENCH_REHEARSAL); rank 0 prints the one line, with the whole job's value and n_gpus = 2, and
+    the sharded lnL equals the single-rank one"""
+    one = _run(["--no-cpu-baseline"])
+    env = dict(os.environ, PHYAMD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--taxa", "24", "--patterns", "3000", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["patterns_per_gpu"] == 1500
+    assert abs(d["config"]["lnL"] - one["config"]["lnL"]) <= 1e-12 * abs(one["config"]["lnL"])
