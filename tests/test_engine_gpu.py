@@ -176,6 +176,20 @@ def test_lazy_rescaling_switch():
         assert np.isinf(lnl) and lnl < 0 and np.all(np.isnan(cg))
 
 
+@pytest.mark.parametrize("shape,T,P,C", [("caterpillar", 5000, 200, 2), ("random", 8000, 150, 4), ("balanced", 4096, 100, 1)])
+def test_very_large_trees(shape, T, P, C):
+    """thousands of taxa (deepest possible, random, and perfectly balanced shapes): schedules, parked-upper slots and the lazy
+    rescaling switch at sizes where every pattern underflows without it; against the oracle"""
+    pb = random_problem(T, P, C, seed=T, shape=shape, gaps=0.02, rescale=2)
+    ref = pb.gradient()
+    assert ref["rescaled"]
+    with engine_from_problem(pb, rescale=RESCALE_AUTO) as e:
+        lnl, cg = e.gradient()
+        assert e.rescaling
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        assert np.abs(cg - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+
+
 def test_medium_problem_and_shard_additivity():
     """cfg2-like shape at reduced size vs the oracle, then the sharding property used for multi-GPU:
     lnL and the per-category gradient are sums over disjoint pattern shards."""
