@@ -189,11 +189,14 @@ int phyamd_parameter_gradient_device(phyamd_engine *e, int flags, double *device
 int phyamd_root_frequency_term(phyamd_engine *e, double *out /* [S] */);
 /* The optimiser's fast path (_calculate_uppper / dlnldt_uppper / d2lnldt2_uppper, treelikelihood.c:2196-2335, 2592-2686):
  * lnL and its first two derivatives with respect to the length of ONE branch, evaluated at a TRIAL length from the upper
- * and lower partials that meet on the branch -- O(patterns) work per trial instead of a tree sweep.  Needs
- * phyamd_set_keep_partials(1) and a phyamd_gradient call for the current parameters (which leaves every upper partial
- * resident); every state count, rescaled evaluations included (their stored partials are anchored on the per-pattern lnL
- * they belong to).  Any of lnl / d1 / d2 may be NULL.  The engine's branch lengths are not
- * changed: accept a length with phyamd_set_branch_length and re-evaluate. */
+ * and lower partials that meet on the branch -- O(patterns) work per trial instead of a tree sweep.  Every state count,
+ * rescaled evaluations included (their stored partials are anchored on the per-pattern lnL they belong to).
+ * The upper partial comes from the last phyamd_gradient if phyamd_set_keep_partials(1) left it resident; otherwise pending
+ * changes are evaluated first (single changed branches: only their paths to the root) and the one upper the branch needs is
+ * rebuilt by a walk down its path from the root (node_upper / update_upper of the reference, treelikelihood.c:1737-1771) and
+ * kept until partials change again -- so the reference's loop "trials of one branch, accept (phyamd_set_branch_length), next
+ * branch" (optimizer.c:116-150) costs a path per branch, not a sweep.  Any of lnl / d1 / d2 may be NULL.  The engine's branch
+ * lengths are not changed by this call. */
 int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, double *lnl, double *d1, double *d2);
 int phyamd_synchronize(phyamd_engine *e);
 

@@ -217,6 +217,11 @@ struct phyamd_engine {
 	double *d_pbuf = nullptr;        // tree-walk G2: [UTpi 16 | Uinv 16 | utab 64]
 	double *d_Fw = nullptr;          // tree-walk G2: [N][C][20] w_c F_ab(t_n r_c), l_a e^{l_a t_n r_c}
 	double *d_gacc = nullptr;        // tree-walk G2: [16][slabs * C] per-wave eigen-basis sums, then [16] totals
+	// phyamd_branch_log_likelihood without resident uppers: the one upper it needs is rebuilt by a root-to-node path walk
+	std::vector<int> node_kind;      // CH_* of every node in the current schedule
+	PathStep *d_path_steps = nullptr;
+	double *d_path_upper = nullptr, *d_path_tmp = nullptr, *d_path_lower = nullptr;  // one node partial each
+	int path_node = -1;              // node whose upper d_path_upper holds (-1: none); dropped whenever partials are recomputed
 	double *d_branch = nullptr;      // phyamd_branch_log_likelihood: [C][3][16] matrices | [3][blocks] partial sums | [3]
 	bool upper_fold = false;         // the stored uppers carry the root frequencies (last gradient call used FOLD)
 	double *d_rf_part = nullptr;     // [S][blocks] partial sums of k_root_frequency_term, then [S]
@@ -320,6 +325,8 @@ int build_schedule(phyamd_engine *e) {
 				kind[n] = CH_DEEP;  // both children are tips or fringe: 4-6 tips below, rebuilt in registers wherever its partial is needed
 		}
 	}
+	e->node_kind = kind;
+	e->path_node = -1;
 	// stored lower arrays: core nodes in id order
 	e->core_index.assign(N, -1);
 	e->core_count = 0;
@@ -1000,6 +1007,7 @@ int run_lower(phyamd_engine *e, bool need_host_check) {
 		e->prof_with_upper = false;
 		return PHYAMD_OK;
 	}
+	e->path_node = -1;  // partials are about to change
 	std::vector<uint8_t> dirty;
 	if (incremental) {
 		// only single branch lengths changed since the stored partials were computed: recompute the core nodes on the paths
@@ -1483,7 +1491,7 @@ void phyamd_destroy(phyamd_engine *e) {
 	if (!e) return;
 	(void)hipSetDevice(e->device);
 	if (e->stream) (void)hipStreamSynchronize(e->stream);
-	for (void *p : {(void *)e->d_branch, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_imgs, (void *)e->d_tipmask, (void *)e->d_tip_all, (void *)e->d_weights_all, (void *)e->d_plk_all, (void *)e->d_total, (void *)e->d_tipsets, (void *)e->d_pg_nodes, (void *)e->d_pg_core, (void *)e->d_pg_den, (void *)e->d_pg_Gw, (void *)e->d_pg_B, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
+	for (void *p : {(void *)e->d_branch, (void *)e->d_path_steps, (void *)e->d_path_upper, (void *)e->d_path_tmp, (void *)e->d_path_lower, (void *)e->d_Bw, (void *)e->d_pbuf, (void *)e->d_Fw, (void *)e->d_gacc, (void *)e->d_gen_scratch, (void *)e->d_rf_part, (void *)e->d_B, (void *)e->d_dpm, (void *)e->d_dptab, (void *)e->d_ppart, (void *)e->d_imgs, (void *)e->d_tipmask, (void *)e->d_tip_all, (void *)e->d_weights_all, (void *)e->d_plk_all, (void *)e->d_total, (void *)e->d_tipsets, (void *)e->d_pg_nodes, (void *)e->d_pg_core, (void *)e->d_pg_den, (void *)e->d_pg_Gw, (void *)e->d_pg_B, (void *)e->d_lower, (void *)e->d_upper, (void *)e->d_mats, (void *)e->d_dmats, (void *)e->d_model, (void *)e->d_Q, (void *)e->d_Lc, (void *)e->d_inv_part, (void *)e->d_tiptab,
 	                (void *)e->d_freqs, (void *)e->d_rates, (void *)e->d_props, (void *)e->d_lengths, (void *)e->d_weights, (void *)e->d_plk, (void *)e->d_wl,
 	                (void *)e->d_lscale, (void *)e->d_lnl_part, (void *)e->d_gpart, (void *)e->d_result, (void *)e->d_explicit, (void *)e->d_row_valid,
 	                (void *)e->d_lower_ops, (void *)e->d_upper_ops, (void *)e->d_walk_lower_ops, (void *)e->d_walk_upper_ops, (void *)e->d_inc_ops, (void *)e->d_Qpi})
@@ -1945,15 +1953,103 @@ int phyamd_root_frequency_term(phyamd_engine *e, double *out) {
 	return PHYAMD_OK;
 }
 
+// the sibling subtree `s` as child_message / PathStep take it
+static void describe_subtree(const phyamd_engine *e, int s, PathStep &st) {
+	st.kind = e->node_kind[s];
+	st.node = s;
+	st.core = e->core_index[s];
+	st.t0 = st.t1 = st.t2 = st.inner = -1;
+	if (st.kind == CH_CHERRY) {
+		st.t0 = e->left[s];
+		st.t1 = e->right[s];
+	} else if (st.kind == CH_CHERRY_TIP) {
+		const int l = e->left[s], r = e->right[s];
+		st.inner = l < e->T ? r : l;
+		st.t2 = l < e->T ? l : r;
+		st.t0 = e->left[st.inner];
+		st.t1 = e->right[st.inner];
+	}
+}
+
+// upper partial of `node` into d_path_upper (and, for a node without a stored lower partial, that partial into d_path_lower)
+static int rebuild_path_upper(phyamd_engine *e, int node) {
+	int rc;
+	const size_t npd = node_partial_doubles(e);
+	if (!e->d_path_upper && ((rc = dev_alloc(e, &e->d_path_upper, npd)) || (rc = dev_alloc(e, &e->d_path_lower, npd)) ||
+	                         (rc = dev_alloc(e, &e->d_path_steps, (size_t)e->N))))
+		return rc;
+	if (e->generic && !e->d_path_tmp && (rc = dev_alloc(e, &e->d_path_tmp, npd))) return rc;
+	std::vector<int> path;  // node, parent, ..., root
+	for (int a = node; a >= 0; a = e->parent[a]) path.push_back(a);
+	const int m = (int)path.size() - 1;  // steps
+	if (!e->generic) {
+		std::vector<PathStep> steps(m);
+		for (int j = 0; j < m; j++) {
+			const int par = path[m - j], child = path[m - j - 1];
+			steps[j].mat = par == e->root ? -1 : par;
+			describe_subtree(e, e->left[par] == child ? e->right[par] : e->left[par], steps[j]);
+		}
+		HIP_TRY(hipMemcpyAsync(e->d_path_steps, steps.data(), sizeof(PathStep) * m, hipMemcpyHostToDevice, e->stream));
+		const dim3 grid((e->P + WAVE - 1) / WAVE), block(WAVE, e->C);
+		if (e->scaling_on)
+			hipLaunchKernelGGL(k_path_upper4<true>, grid, block, sizeof(double) * e->C * WAVE, e->stream, e->d_path_steps, m, e->T, e->P, e->C, e->d_tipmask, e->d_lower,
+			                   e->d_mats, e->d_tiptab, e->d_path_upper);
+		else
+			hipLaunchKernelGGL(k_path_upper4<false>, grid, block, 0, e->stream, e->d_path_steps, m, e->T, e->P, e->C, e->d_tipmask, e->d_lower, e->d_mats,
+			                   e->d_tiptab, e->d_path_upper);
+		if (node >= e->T && e->core_index[node] < 0) {  // fringe / DEEP node: its own partial is not stored either
+			PathStep self;
+			describe_subtree(e, node, self);
+			hipLaunchKernelGGL(k_unstored_partial4, grid, block, 0, e->stream, self.kind, node, self.t0, self.t1, self.t2, self.inner, e->T, e->P, e->C, e->d_tipmask,
+			                   e->d_mats, e->d_tiptab, e->d_path_lower);
+		}
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(e->stream));  // `steps` is a stack-lifetime buffer
+	} else {
+		// one launch per step, ping-pong between two buffers so that the last step lands in d_path_upper
+		const size_t msz = (size_t)e->C * e->S * e->S;
+		const int pb = (e->P + 255) / 256;
+		double *cur = nullptr;
+		for (int j = 0; j < m; j++) {
+			const int par = path[m - j], child = path[m - j - 1];
+			const int sib = e->left[par] == child ? e->right[par] : e->left[par];
+			double *dst = ((m - 1 - j) & 1) ? e->d_path_tmp : e->d_path_upper;
+			const double *sp = sib < e->T ? nullptr : e->d_lower + (size_t)e->core_index[sib] * npd;
+			hipLaunchKernelGGL(k_path_step_gen, dim3(pb), dim3(256), 0, e->stream, e->P, e->Pp, e->S, e->C, par == e->root ? (const double *)nullptr : e->d_mats + (size_t)par * msz,
+			                   par == e->root ? (const double *)nullptr : cur, e->d_mats + (size_t)sib * msz, sp,
+			                   sib < e->T ? e->d_tipmask + (size_t)sib * e->P : (const uint8_t *)nullptr, e->d_tipsets, dst);
+			if (e->scaling_on) hipLaunchKernelGGL(k_path_scale_gen, dim3(pb), dim3(256), 0, e->stream, e->P, e->Pp, e->S, e->C, dst);
+			cur = dst;
+		}
+		HIP_TRY(hipGetLastError());
+	}
+	e->path_node = node;
+	return PHYAMD_OK;
+}
+
 int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, double *lnl, double *d1, double *d2) {
 	CHECK_ENGINE(e);
 	NOT_TILED(e, "the single-branch evaluation");
 	if (node < 0 || node >= e->N || node == e->root) return fail(PHYAMD_EINVAL, "node %d has no branch", node);
-	if (!e->keep_partials || !e->upper_valid)
-		return fail(PHYAMD_EINVAL, "the single-branch evaluation needs the partials of phyamd_gradient with phyamd_set_keep_partials(1)");
 	if (!e->have_eigen) return fail(PHYAMD_EINVAL, "the single-branch evaluation needs the eigen system (phyamd_set_eigen)");
 	int rc;
 	if ((rc = bind_device(e))) return rc;
+	const size_t npd = node_partial_doubles(e);
+	// the two partials that meet on the branch: resident after a keep-partials gradient, else the upper one is rebuilt by a
+	// walk down the path from the root (pending changes are evaluated first; the result is kept until partials change)
+	const bool resident = e->keep_partials && e->upper_valid;
+	const double *up, *low;
+	int fold = 0;
+	if (resident) {
+		up = e->d_upper + (size_t)e->upper_slot[node] * npd;
+		low = node < e->T ? nullptr : e->d_lower + (size_t)e->core_index[node] * npd;
+		fold = e->upper_fold ? 1 : 0;
+	} else {
+		if ((rc = run_lower(e, true))) return rc;
+		if (e->path_node != node && (rc = rebuild_path_upper(e, node))) return rc;
+		up = e->d_path_upper;
+		low = node < e->T ? nullptr : (e->core_index[node] >= 0 ? e->d_lower + (size_t)e->core_index[node] * npd : e->d_path_lower);
+	}
 	const int C = e->C, S = e->S, S2 = S * S;
 	const int per_block = e->generic ? 256 : WAVE, nb = (e->P + per_block - 1) / per_block;
 	const size_t msz = (size_t)C * (e->generic ? 4 : 3) * S2, need = msz + (size_t)3 * nb + 3;
@@ -1983,20 +2079,17 @@ int phyamd_branch_log_likelihood(phyamd_engine *e, int node, double length, doub
 	// rescaled evaluations: the per-pattern lnL of the resident evaluation anchors the stored (scaled) partials
 	const double *plk = e->scaling_on ? e->d_plk : nullptr;
 	const double *m0 = e->d_mats + (size_t)node * C * S2;
-	const size_t npd = node_partial_doubles(e);
-	const double *up = e->d_upper + (size_t)e->upper_slot[node] * npd;
-	const double *low = node < e->T ? nullptr : e->d_lower + (size_t)e->core_index[node] * npd;
 	double *part = e->d_branch + msz;
 	if (e->generic) {
 		if (plk)
 			for (int c = 0; c < C; c++)
 				HIP_TRY(hipMemcpyAsync(e->d_branch + (size_t)c * stride + 3 * S2, m0 + (size_t)c * S2, sizeof(double) * S2, hipMemcpyDeviceToDevice, e->stream));
 		hipLaunchKernelGGL(k_branch_eval_gen, dim3(nb), dim3(256), 0, e->stream, node, e->T, e->P, e->Pp, S, C, up, low, e->d_tipmask, e->d_tipsets, e->d_branch,
-		                   e->d_freqs, e->upper_fold ? 1 : 0, e->d_props, e->d_weights, plk, part);
+		                   e->d_freqs, fold, e->d_props, e->d_weights, plk, part);
 	} else
 		hipLaunchKernelGGL(k_branch_eval4, dim3(nb), dim3(WAVE, C), sizeof(double) * 4 * C * WAVE, e->stream, e->P, C, up, low,
-		                   node < e->T ? e->d_tipmask + (size_t)node * e->P : (const uint8_t *)nullptr, e->d_branch, e->d_freqs, e->upper_fold ? 1 : 0,
-		                   e->d_props, e->d_weights, plk, m0, part);
+		                   node < e->T ? e->d_tipmask + (size_t)node * e->P : (const uint8_t *)nullptr, e->d_branch, e->d_freqs, fold, e->d_props, e->d_weights, plk,
+		                   m0, part);
 	hipLaunchKernelGGL(k_reduce_rows, dim3(3), dim3(64), 0, e->stream, part, nb, (const uint8_t *)nullptr, part + (size_t)3 * nb);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(e->h_result, part + (size_t)3 * nb, sizeof(double) * 3, hipMemcpyDeviceToHost, e->stream));

@@ -37,6 +37,28 @@ for n in rng.choice([i for i in range(2 * T - 1) if i != tree.root], size=8, rep
     t0 = time.perf_counter(); e.restore(); lb = e.log_likelihood(); tr = time.perf_counter() - t0
     out["mcmc"].append({"node": int(n), "store_ms": ts * 1e3, "propose_eval_ms": tp * 1e3, "restore_eval_ms": tr * 1e3,
                         "restore_launches": e.profile()["lower_launches"], "restored_rel": abs(lb - lchk) / abs(lchk)})
+# the optimiser's loop (optimizer.c:116-150): per branch a first trial (pending change evaluated on its path to the
+# root + the branch's upper rebuilt by a walk down from the root), further trials of the same branch, then the accepted length
+e2 = Engine(T, P, 4, C, rescale=RESCALE_AUTO)
+e2.set_topology(tree.left, tree.right, tree.root); e2.set_branch_lengths(tree.length); e2.set_eigen(ev, U, Ui)
+e2.set_frequencies(np.array(bench.GTR_FREQS)); e2.set_category_rates(rates, np.full(C, 0.25)); e2.set_pattern_weights(np.ones(P))
+for t in range(T): e2.set_tip_states(t, states[t])
+e2.log_likelihood()
+out["optimizer"] = []
+bl2 = tree.length.copy()
+for n in rng.choice([i for i in range(2 * T - 1) if i != tree.root], size=10, replace=False):
+    t0 = time.perf_counter(); a = e2.branch_log_likelihood(int(n), bl2[n]); tf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for f in (0.7, 1.3, 1.1, 0.95): e2.branch_log_likelihood(int(n), bl2[n] * f)
+    tt = (time.perf_counter() - t0) / 4
+    bl2[n] *= 0.95
+    t0 = time.perf_counter(); e2.set_branch_length(int(n), bl2[n]); ts = time.perf_counter() - t0
+    out["optimizer"].append({"node": int(n), "first_trial_ms": tf * 1e3, "further_trial_ms": tt * 1e3, "accept_ms": ts * 1e3})
+e2.update_all_nodes(); chk = e2.log_likelihood()
+a = e2.branch_log_likelihood(5, bl2[5])
+out["optimizer_check_rel"] = abs(a[0] - chk) / abs(chk)
+out["median_first_trial_ms"] = float(np.median([m["first_trial_ms"] for m in out["optimizer"][1:]]))
+out["median_further_trial_ms"] = float(np.median([m["further_trial_ms"] for m in out["optimizer"]]))
 out["median_restore_eval_ms"] = float(np.median([m["restore_eval_ms"] for m in out["mcmc"]]))
 out["median_single_ms"] = float(np.median([s["ms"] for s in out["single"]]))
 print(json.dumps(out))

@@ -756,8 +756,6 @@ def test_single_branch_evaluation(S, T, P, C, fold, rescale):
     flags = GRAD_FOLD_ROOT_FREQS if fold else 0
     mode = RESCALE_ALWAYS if rescale else RESCALE_NEVER
     with engine_from_problem(pb, rescale=mode) as e, engine_from_problem(pb, rescale=mode) as full:
-        with pytest.raises(EngineError):
-            e.branch_log_likelihood(0, 0.1)  # partials are not resident yet
         e.set_keep_partials(True)
         lnl0, cg = e.gradient(flags)
         bg = po.branch_gradient_from_cat(cg, pb.cat_rates, pb.cat_props)
@@ -783,9 +781,39 @@ def test_single_branch_evaluation(S, T, P, C, fold, rescale):
                 assert abs((d1p - d1m) / (2 * h) - d2t) <= 1e-5 * max(1.0, abs(d2t))
         with pytest.raises(EngineError):
             e.branch_log_likelihood(pb.root, 0.1)
-        e.set_branch_length(0, 0.5)  # the partials no longer belong to the parameters
-        with pytest.raises(EngineError):
-            e.branch_log_likelihood(0, 0.5)
+
+
+@pytest.mark.parametrize("S,T,P,C,rescale", [(4, 60, 333, 4, 0), (4, 33, 100, 1, 0), (4, 70, 150, 4, 1), (20, 14, 90, 2, 0), (61, 9, 33, 1, 0), (20, 50, 40, 2, 1)])
+def test_single_branch_evaluation_without_resident_uppers(S, T, P, C, rescale):
+    """The optimiser's loop as the reference runs it (optimizer.c:116-150): for branch after branch, trial lengths, then the
+    accepted length is set and the next branch follows.  No keep-partials gradient in between: the one upper partial a
+    branch needs is rebuilt by a walk down its path from the root (fringe, DEEP and stored siblings alike), pending single-branch
+    changes recompute only their paths to the root.  Every value against a fresh full recomputation."""
+    pb = random_problem(T, P, C, seed=90 + T + S, S=S, gaps=0.03, bl=(0.3, 0.9) if rescale else (0.01, 0.1), rescale=rescale)
+    mode = RESCALE_ALWAYS if rescale else RESCALE_NEVER
+    rng = np.random.default_rng(T)
+    with engine_from_problem(pb, rescale=mode) as e, engine_from_problem(pb, rescale=mode) as full:
+        bl = pb.branch_lengths.copy()
+        order = [n for n in range(pb.N) if n != pb.root]
+        rng.shuffle(order)
+        for n in order[:12]:  # tips, cherries' tips, fringe and DEEP nodes, stored nodes: whatever the shuffle brings
+            for t in (0.6 * bl[n], 1.5 * bl[n] + 0.01):
+                lt, d1, d2 = e.branch_log_likelihood(n, t)
+                trial = bl.copy()
+                trial[n] = t
+                full.set_branch_lengths(trial)
+                ref_lnl, ref_cg = full.gradient()
+                assert abs(lt - ref_lnl) <= 1e-11 * abs(ref_lnl), (n, t)
+                ref_bg = po.branch_gradient_from_cat(ref_cg, pb.cat_rates, pb.cat_props)
+                assert abs(d1 - ref_bg[n]) <= 1e-9 * max(1.0, np.abs(ref_bg).max()), (n, t)
+            bl[n] = 1.5 * bl[n] + 0.01  # accept the last trial: the next branch sees it
+            e.set_branch_length(n, bl[n])
+        assert abs(e.log_likelihood() - ref_lnl) <= 1e-11 * abs(ref_lnl)
+        e.set_profiling(True)
+        n = order[20 % len(order)]
+        e.branch_log_likelihood(n, bl[n])
+        e.branch_log_likelihood(n, 1.1 * bl[n])  # same branch again: the rebuilt upper is reused, nothing is recomputed
+        assert e.profile()["lower_launches"] == 0
 
 
 # ---------------------------------------------------------------------------------------------------------
