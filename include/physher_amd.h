@@ -68,8 +68,8 @@ typedef struct {
 	                             tiles through ONE set of partial arrays: tip data, weights and per-pattern lnL of all tiles
 	                             stay resident, per-tile sums are added in tile order (phyamd_profile.tiles tells how many).
 	                             lnL, gradients and parameter gradients work as usual; calls that need resident partials
-	                             (phyamd_get_partials, phyamd_set_keep_partials, phyamd_store, phyamd_branch_log_likelihood,
-	                             phyamd_root_invariant_term) return PHYAMD_EUNSUPPORTED, and every evaluation recomputes every
+	                             (phyamd_get_partials, phyamd_set_keep_partials, phyamd_store, phyamd_branch_log_likelihood)
+	                             return PHYAMD_EUNSUPPORTED, and every evaluation recomputes every
 	                             tile.  PHYAMD_ENOMEM if even a 256-pattern tile does not fit. */
 	void *stream;           /* hipStream_t to run on, NULL = engine-owned stream */
 } phyamd_config;

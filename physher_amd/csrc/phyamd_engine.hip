@@ -147,6 +147,7 @@ struct phyamd_engine {
 	// pattern tiling (cfg.max_device_bytes): P = patterns per tile (what every kernel sees), Ptot = the caller's count;
 	// tip data, weights and per-pattern lnL of all tiles stay resident, the partial arrays are reused tile after tile
 	int Ptot = 0, tiles = 1;
+	bool tiled_eval_done = false;
 	bool tiled_root_term = false;     // d_result holds the summed root frequency term of a tiled parameter gradient
 	uint8_t *d_tip_all = nullptr;      // [T][Ptot]
 	double *d_weights_all = nullptr, *d_plk_all = nullptr, *d_total = nullptr;
@@ -1202,6 +1203,21 @@ int launch_root_frequency_term(phyamd_engine *e, double *dst) {
 	return PHYAMD_OK;
 }
 
+// sum_k (w_k / L_k) sum_i pi_i (p_root[cat 0] - mean of p_root[cat >= 1]) of the resident root partial -> dst (device)
+int launch_root_invariant_term(phyamd_engine *e, double *dst) {
+	int rc;
+	const int nb = (e->P + 255) / 256;
+	if (!e->d_inv_part && (rc = dev_alloc(e, &e->d_inv_part, (size_t)nb + 1))) return rc;
+	const double *root = e->d_lower + (size_t)e->core_index[e->root] * node_partial_doubles(e);
+	const size_t cat_stride = e->generic ? (size_t)e->S * e->Pp : (size_t)e->P * e->S;
+	const size_t pat_stride = e->generic ? 1 : (size_t)e->S, state_stride = e->generic ? (size_t)e->Pp : 1;
+	hipLaunchKernelGGL(k_root_invariant_term, dim3(nb), dim3(256), 0, e->stream, e->P, e->S, e->C, root, cat_stride, pat_stride, state_stride, e->d_freqs,
+	                   e->d_props, e->d_weights, e->d_inv_part);
+	hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_inv_part, nb, (const uint8_t *)nullptr, dst ? dst : e->d_inv_part + nb);
+	HIP_TRY(hipGetLastError());
+	return PHYAMD_OK;
+}
+
 int run_gradient(phyamd_engine *e, int flags, bool with_params = false) {
 	int rc;
 	e->upper_fold = (flags & PHYAMD_GRAD_FOLD_ROOT_FREQS) != 0;
@@ -1281,6 +1297,8 @@ int run_tiled(phyamd_engine *e, int mode, int flags) {
 	if ((rc = bind_device(e))) return rc;
 	const int n = mode == 0 ? 1 : 1 + e->N * e->C + (mode == 2 ? e->np + e->S : 0);
 	HIP_TRY(hipMemsetAsync(e->d_total, 0, sizeof(double) * n, e->stream));
+	double *inv_total = e->d_total + (size_t)e->N * e->C + 2 * PHYAMD_MAX_PARAMETERS;  // the last entry of the allocation: the +I root term
+	HIP_TRY(hipMemsetAsync(inv_total, 0, sizeof(double), e->stream));
 	const uint8_t unknown = e->generic ? (uint8_t)e->S : (uint8_t)0xF;
 	for (int t = 0; t < e->tiles; t++) {
 		const size_t off = (size_t)t * e->P;
@@ -1294,11 +1312,16 @@ int run_tiled(phyamd_engine *e, int mode, int flags) {
 		e->all_dirty = true;
 		if ((rc = mode == 0 ? run_lower(e, true) : run_gradient(e, flags, mode == 2))) return rc;
 		hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, e->d_result, e->d_total);
+		if (e->C >= 2) {  // the +I site-model gradient needs this tile's root partial while it is resident
+			if ((rc = launch_root_invariant_term(e, nullptr))) return rc;
+			hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, e->stream, 1, e->d_inv_part + (e->P + 255) / 256, inv_total);
+		}
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipMemcpyAsync(e->d_plk_all + off, e->d_plk, sizeof(double) * w, hipMemcpyDeviceToDevice, e->stream));
 	}
 	HIP_TRY(hipMemcpyAsync(e->d_result, e->d_total, sizeof(double) * n, hipMemcpyDeviceToDevice, e->stream));
 	e->tiled_root_term = mode == 2;
+	e->tiled_eval_done = true;
 	e->lower_valid = false;  // the resident partials are those of the last tile only
 	e->all_dirty = true;
 	e->upper_valid = false;
@@ -2114,22 +2137,20 @@ int phyamd_compress_patterns(int device, int32_t taxon_count, int64_t site_count
 
 int phyamd_root_invariant_term(phyamd_engine *e, double *out) {
 	CHECK_ENGINE(e);
-	NOT_TILED(e, "the +I root term");
 	if (!out) return fail(PHYAMD_EINVAL, "null out");
 	if (e->C < 2) return fail(PHYAMD_EINVAL, "the invariant-class term needs at least two categories");
 	int rc;
 	if ((rc = bind_device(e))) return rc;
 	if ((rc = check_ready(e))) return rc;
-	const int nb = (e->P + 255) / 256;
-	if (!e->d_inv_part && (rc = dev_alloc(e, &e->d_inv_part, (size_t)nb + 1))) return rc;
-	const double *root = e->d_lower + (size_t)e->core_index[e->root] * node_partial_doubles(e);
-	const size_t cat_stride = e->generic ? (size_t)e->S * e->Pp : (size_t)e->P * e->S;
-	const size_t pat_stride = e->generic ? 1 : (size_t)e->S, state_stride = e->generic ? (size_t)e->Pp : 1;
-	hipLaunchKernelGGL(k_root_invariant_term, dim3(nb), dim3(256), 0, e->stream, e->P, e->S, e->C, root, cat_stride, pat_stride, state_stride, e->d_freqs,
-	                   e->d_props, e->d_weights, e->d_inv_part);
-	hipLaunchKernelGGL(k_reduce_rows, dim3(1), dim3(64), 0, e->stream, e->d_inv_part, nb, (const uint8_t *)nullptr, e->d_inv_part + nb);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(e->h_result, e->d_inv_part + nb, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+	const double *src;
+	if (e->tiles > 1) {  // summed over the tiles by the last evaluation (one entry behind everything else in the total)
+		if (!e->tiled_eval_done) return fail(PHYAMD_EINVAL, "no evaluation has been run yet");
+		src = e->d_total + (size_t)e->N * e->C + 2 * PHYAMD_MAX_PARAMETERS;
+	} else {
+		if ((rc = launch_root_invariant_term(e, nullptr))) return rc;
+		src = e->d_inv_part + (e->P + 255) / 256;
+	}
+	HIP_TRY(hipMemcpyAsync(e->h_result, src, sizeof(double), hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	*out = e->h_result[0];
 	return PHYAMD_OK;
