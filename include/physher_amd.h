@@ -76,6 +76,19 @@ typedef struct {
 
 /* --- life cycle: new_SingleTreeLikelihood / free_SingleTreeLikelihood (treelikelihood.c:1007-1185) --- */
 int phyamd_create(const phyamd_config *cfg, phyamd_engine **out);
+/* The same engine with its site patterns sharded over `device_count` GPUs of this node, inside ONE process: shard s
+ * is a complete engine on device_ids[s] (NULL: devices 0 .. device_count-1) that owns the contiguous pattern range
+ * [s P / n, (s+1) P / n); tree, branch lengths, eigen system and rates are replicated to every shard, per-pattern arguments
+ * (tip data, weights, per-pattern lnL, partials) are sliced, and every evaluation runs on all shards at once (one host thread per
+ * shard) and returns the per-shard sums added in shard order -- lnL, the [node][category] gradient, parameter sums, root terms:
+ * the "single all-reduce of the per-block lnL and gradient vector", done on the host where the caller wants the 64 KB anyway.
+ * Every other call of this header works on the handle unchanged, except the *_device evaluations (their output lives on one
+ * device: PHYAMD_EUNSUPPORTED for device_count > 1; the one-process-per-GPU form of the same sharding -- bench.py under
+ * torchrun -- is what uses them, with one RCCL all-reduce).  cfg->device is ignored, cfg->stream must be NULL,
+ * cfg->max_device_bytes applies per shard.  The same device may be listed more than once. */
+int phyamd_create_sharded(const phyamd_config *cfg, int32_t device_count, const int32_t *device_ids, phyamd_engine **out);
+/* number of shards behind a handle (1 for phyamd_create) */
+int phyamd_shard_count(phyamd_engine *e);
 void phyamd_destroy(phyamd_engine *e);
 const char *phyamd_last_error(void);
 /* version of this ABI (bumped on any signature change) */
@@ -138,6 +151,10 @@ int phyamd_set_category_rates(phyamd_engine *e, const double *rates /* [C] */, c
 /* Optional: explicit matrices [C][S][S] for one node (closed-form models: jc69.c:73-79, hky.c:230-273).
  * Cleared by phyamd_set_eigen. */
 int phyamd_set_node_matrices(phyamd_engine *e, int node, const double *matrices);
+/* The same for every node at once: matrices [2T-1][C][S][S] by node id (the root's entry is ignored), one upload.  What
+ * _calculate_partials does per node with m->p_t (treelikelihood.c:1671-1691) when the caller wants the model's own closed-form
+ * arithmetic bit for bit. */
+int phyamd_set_matrices(phyamd_engine *e, const double *matrices);
 /* Rate matrix Q [S][S] (rows sum to 0, normalised like substmodel.c:1135-1143).  The gradient kernels use
  * (dP/dt) p = Q (P p) instead of a second matrix per branch (the reference's dp_dt, substmodel.c:695-723, is the
  * same product).  phyamd_set_eigen derives Q itself; only explicit-matrix users need this call. */
@@ -208,6 +225,9 @@ int phyamd_get_pattern_log_likelihoods(phyamd_engine *e, double *out /* [P] */);
 int phyamd_get_partials(phyamd_engine *e, int node, int upper, double *out);
 int phyamd_get_node_matrices(phyamd_engine *e, int node, int derivative, double *out /* [C][S][S] */);
 int phyamd_is_rescaling(phyamd_engine *e);
+/* SingleTreeLikelihood_use_rescaling (treelikelihood.c:1410-1423) after construction: PHYAMD_RESCALE_ALWAYS / _NEVER switch
+ * at once (the next evaluation recomputes every node), PHYAMD_RESCALE_AUTO keeps the current state and re-arms the lazy switch. */
+int phyamd_set_rescaling(phyamd_engine *e, int policy);
 /* keep every node's upper partials resident after a gradient call (costs memory; off by default) */
 int phyamd_set_keep_partials(phyamd_engine *e, int on);
 

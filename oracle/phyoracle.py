@@ -55,6 +55,11 @@ def encode_alignment(datatype: str, sequences) -> np.ndarray:
     L = lib()
     nsites = len(sequences[0]) // step
     cols = np.empty((nsites, len(sequences)), dtype=np.uint8)
+    if step == 1:  # one symbol per site: a 256-entry table of the C encoder's answers instead of a call per symbol
+        lut = np.array([L.phyo_encode_symbol(dt, bytes([b])) if b else 0 for b in range(256)], dtype=np.uint8)
+        for t, s in enumerate(sequences):
+            cols[:, t] = lut[np.frombuffer(s.encode(), dtype=np.uint8)]
+        return cols
     for t, s in enumerate(sequences):
         b = s.encode()
         for k in range(nsites):

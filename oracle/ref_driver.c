@@ -17,6 +17,7 @@
  *   ref_driver json  <reference-json-file> <out.json>      (run in the dir holding its data files)
  *   ref_driver bench <spec-file> <iters> <warmup>
  *   ref_driver attr  <attr-spec-file> <out.json>           (one discrete trait per taxon, any state count)
+ *   ref_driver branch <spec-file> <out.json>               (lnL, d lnL/dt, d2 lnL/dt2 of single branches at trial lengths)
  *
  * spec-file: "key value" lines:
  *   fasta <path>        newick <path-to-file-with-newick>
@@ -35,6 +36,8 @@
  *   newick <path>             structure i,j,...  (rate index of each upper-, then each lower-triangle entry)
  *   rates r0,r1,...           freqs f0,...       normalize 0|1     categories C   alpha A
  */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdbool.h>
@@ -239,6 +242,7 @@ static built_t build_from_spec(const spec_t *sp) {
 		SingleTreeLikelihood *tlk = new_SingleTreeLikelihood((Tree *)b.mtree->obj, m, (SiteModel *)msm->obj, b.patterns, NULL, sp->tipstates);
 		b.patterns->ref_count++;
 		b.mlike = new_TreeLikelihoodModel("treelikelihood", tlk, b.mtree, mm, msm, NULL);
+		tlk->include_jacobian = false; /* physher.cpp:627: the C constructor leaves it unset */
 		mm->free(mm);
 		msm->free(msm);
 	}
@@ -357,6 +361,17 @@ static built_t build_from_attr_spec(const char *path) {
 
 static void jnum(FILE *o, double v);
 
+/* With tests/integration/physher_device.c in front of libphyc (LD_PRELOAD) the model may be evaluated on the GPU: the CPU-side
+ * partial arrays are then never filled and are not dumped. */
+static int on_device(SingleTreeLikelihood *tlk) {
+	int (*f)(const SingleTreeLikelihood *) = (int (*)(const SingleTreeLikelihood *))dlsym(RTLD_DEFAULT, "SingleTreeLikelihood_on_device");
+	return f ? f(tlk) : 0;
+}
+static int device_rescaling(SingleTreeLikelihood *tlk) {
+	int (*f)(const SingleTreeLikelihood *) = (int (*)(const SingleTreeLikelihood *))dlsym(RTLD_DEFAULT, "SingleTreeLikelihood_device_is_rescaling");
+	return f ? f(tlk) : 0;
+}
+
 static void jarr(FILE *o, const char *key, const double *v, size_t n, bool comma) {
 	fprintf(o, "\"%s\":[", key);
 	for (size_t i = 0; i < n; i++) {
@@ -395,7 +410,7 @@ static void dump_common(FILE *o, Model *mlike) {
 	double lnl = mlike->logP(mlike);
 	fprintf(o, "\"lnl\":");
 	jnum(o, lnl);
-	fprintf(o, ",\n\"rescaled\":%s,\n", tlk->scale ? "true" : "false");
+	fprintf(o, ",\n\"rescaled\":%s,\n", (tlk->scale || device_rescaling(tlk)) ? "true" : "false");
 	jarr(o, "pattern_lk", tlk->pattern_lk, P, true);
 
 	fprintf(o, "\"nodes\":[");
@@ -462,7 +477,7 @@ static void dump_common(FILE *o, Model *mlike) {
 		free(mat);
 	}
 	/* lower partials of the root and of the first internal node, reference layout [C][P][S] */
-	{
+	if (!on_device(tlk)) {
 		int ids[2] = {T, Tree_root(tree)->id};
 		const char *nm[2] = {"partials_first_internal", "partials_root"};
 		for (int q = 0; q < 2; q++) jarr(o, nm[q], tlk->partials[tlk->current_partials_indexes[ids[q]]][ids[q]], (size_t)C * P * S, true);
@@ -479,7 +494,7 @@ static void dump_gradients_unrooted(FILE *o, Model *mlike) {
 	double *g = TreeLikelihood_gradient(mlike);
 	jarr(o, "gradient_tree", g, len, true);
 	/* upper partials of the first internal node and of tip 0 (valid after the gradient call) */
-	{
+	if (!on_device(tlk)) {
 		int T = Tree_tip_count(tlk->tree);
 		size_t sz = (size_t)tlk->cat_count * tlk->sp->count * tlk->m->nstate;
 		int ids[2] = {0, T};
@@ -524,6 +539,48 @@ int main(int argc, char **argv) {
 		dump_common(o, b.mlike);
 		dump_gradients_unrooted(o, b.mlike);
 		fprintf(o, "\"source\":\"physher reference (libphyc no-GSL build) via oracle/ref_driver.c\"\n}\n");
+		fclose(o);
+		return 0;
+	}
+	if (!strcmp(argv[1], "branch")) {
+		/* The optimiser's fast path: lnL and its first two derivatives with respect to ONE branch length at trial
+		 * values, by the reference's own upper-partial protocol (_singleTreeLikelihood_d2logP, treelikelihood.c:469-530):
+		 * full evaluation at the trial length, update_upper_partials, calculate_dldt_uppper, d2lnldt2_uppper. */
+		spec_t sp;
+		read_spec(argv[2], &sp);
+		built_t b = build_from_spec(&sp);
+		SingleTreeLikelihood *tlk = b.mlike->obj;
+		Tree *tree = tlk->tree;
+		const int N = Tree_node_count(tree), T = Tree_tip_count(tree), P = tlk->sp->count;
+		const int right_of_root = Node_id(Node_right(Tree_root(tree)));
+		int pick[4] = {0, T / 2, T, N - 2};
+		const double factor[3] = {1.0, 0.4, 2.5};
+		FILE *o = fopen(argv[3], "w");
+		fprintf(o, "{\"trials\":[");
+		int first = 1;
+		for (int q = 0; q < 4; q++) {
+			int id = pick[q];
+			while (id == right_of_root || id == Node_id(Tree_root(tree))) id--;
+			Node *node = Tree_node(tree, id);
+			const double base = Node_distance(node);
+			for (int f = 0; f < 3; f++) {
+				const double t = base * factor[f];
+				Node_set_distance(node, t);
+				SingleTreeLikelihood_update_all_nodes(tlk);
+				const double lnl = b.mlike->logP(b.mlike);
+				update_upper_partials(tlk, Tree_root(tree), false);
+				double *pl = tlk->pattern_lk + P, *pdl = tlk->pattern_lk + 2 * P;
+				for (int k = 0; k < P; k++) pl[k] = exp(tlk->pattern_lk[k]);
+				calculate_dldt_uppper(tlk, node, pdl);
+				double d1 = 0;
+				for (int k = 0; k < P; k++) d1 += tlk->sp->weights[k] * pdl[k] / pl[k];
+				const double d2 = d2lnldt2_uppper(tlk, node, pl, pdl);
+				fprintf(o, "%s{\"node\":%d,\"length\":%.17g,\"lnl\":%.17g,\"d1\":%.17g,\"d2\":%.17g}", first ? "" : ",", id, t, lnl, d1, d2);
+				first = 0;
+			}
+			Node_set_distance(node, base);
+		}
+		fprintf(o, "],\"rescaled\":%s,\"source\":\"physher reference via oracle/ref_driver.c branch mode\"}\n", tlk->scale ? "true" : "false");
 		fclose(o);
 		return 0;
 	}

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PHYAMD_LIB: load another build of the same ABI (A/B experiments with kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("PHYAMD_LIB") or os.path.join(_HERE, "libphysher_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, EINVAL, EDEVICE, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
 RESCALE_NEVER, RESCALE_ALWAYS, RESCALE_AUTO = 0, 1, 2
@@ -39,6 +39,8 @@ class Profile(C.Structure):
 _P = C.c_void_p
 SYMBOLS = [
     ("phyamd_create", C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    ("phyamd_create_sharded", C.c_int, [C.POINTER(Config), C.c_int32, _P, C.POINTER(_P)]),
+    ("phyamd_shard_count", C.c_int, [_P]),
     ("phyamd_destroy", None, [_P]),
     ("phyamd_last_error", C.c_char_p, []),
     ("phyamd_abi_version", C.c_int, []),
@@ -53,6 +55,7 @@ SYMBOLS = [
     ("phyamd_set_frequencies", C.c_int, [_P, _P]),
     ("phyamd_set_category_rates", C.c_int, [_P, _P, _P]),
     ("phyamd_set_node_matrices", C.c_int, [_P, C.c_int, _P]),
+    ("phyamd_set_matrices", C.c_int, [_P, _P]),
     ("phyamd_set_rate_matrix", C.c_int, [_P, _P]),
     ("phyamd_log_likelihood", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("phyamd_gradient", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), _P]),
@@ -70,6 +73,7 @@ SYMBOLS = [
     ("phyamd_get_partials", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("phyamd_get_node_matrices", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("phyamd_is_rescaling", C.c_int, [_P]),
+    ("phyamd_set_rescaling", C.c_int, [_P, C.c_int]),
     ("phyamd_set_keep_partials", C.c_int, [_P, C.c_int]),
     ("phyamd_set_profiling", C.c_int, [_P, C.c_int]),
     ("phyamd_get_profile", C.c_int, [_P, C.POINTER(Profile)]),

@@ -22,15 +22,25 @@ class Engine:
     """One tree-likelihood instance on one GPU (the device analogue of physher's SingleTreeLikelihood)."""
 
     def __init__(self, tip_count, pattern_count, state_count=4, category_count=1, device=-1, rescale=RESCALE_AUTO,
-                 max_device_bytes=0, stream=None):
+                 max_device_bytes=0, stream=None, devices=None):
+        """devices: list of HIP device ordinals -> the patterns are sharded over them inside this process
+        (phyamd_create_sharded; the same ordinal may repeat); None -> one engine on `device`."""
         self._lib = _lib.load()
         self.T, self.P, self.S, self.C = int(tip_count), int(pattern_count), int(state_count), int(category_count)
         self.N = 2 * self.T - 1
         cfg = _lib.Config(self.T, self.P, self.S, self.C, device, rescale, max_device_bytes, stream)
         h = C.c_void_p()
         self._h = None
-        self._check(self._lib.phyamd_create(C.byref(cfg), C.byref(h)))
+        if devices is None:
+            self._check(self._lib.phyamd_create(C.byref(cfg), C.byref(h)))
+        else:
+            ids = np.ascontiguousarray(devices, dtype=np.int32)
+            self._check(self._lib.phyamd_create_sharded(C.byref(cfg), len(ids), _ptr(ids), C.byref(h)))
         self._h = h
+
+    @property
+    def shard_count(self):
+        return self._lib.phyamd_shard_count(self._h)
 
     def _check(self, rc):
         if rc != 0:
@@ -106,6 +116,12 @@ class Engine:
         a = _f64(mats)
         assert a.shape == (self.C, self.S, self.S)
         self._check(self._lib.phyamd_set_node_matrices(self._h, node, _ptr(a)))
+
+    def set_matrices(self, mats):
+        """explicit P(t) of every node at once: [N][C][S][S] by node id (the root's entry is ignored)"""
+        a = _f64(mats)
+        assert a.shape == (self.N, self.C, self.S, self.S)
+        self._check(self._lib.phyamd_set_matrices(self._h, _ptr(a)))
 
     def set_rate_matrix(self, Q):
         a = _f64(Q)
@@ -205,6 +221,9 @@ class Engine:
     @property
     def rescaling(self):
         return bool(self._lib.phyamd_is_rescaling(self._h))
+
+    def set_rescaling(self, policy):
+        self._check(self._lib.phyamd_set_rescaling(self._h, int(policy)))
 
     def set_keep_partials(self, on=True):
         self._check(self._lib.phyamd_set_keep_partials(self._h, int(on)))

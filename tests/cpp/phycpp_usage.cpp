@@ -8,7 +8,11 @@
 #include <string>
 #include <vector>
 
-#include "phycpp_amd/physher.hpp"  // reference: #include "phycpp/physher.hpp"
+#ifdef PHYCPP_REFERENCE
+#include "phycpp/physher.hpp"  // the reference's own wrapper (oracle/Makefile: phycpp_usage_ref, run on the device through seam A)
+#else
+#include "phycpp_amd/physher.hpp"
+#endif
 
 static void read_fasta(const std::string &path, std::vector<std::pair<std::string, std::string>> &aln) {
 	std::ifstream f(path);

@@ -281,12 +281,34 @@ def run_attr_case(name, o):
     print(f"{name}: K={data['state_count']} lnL={data['lnl']!r} gradient_all={len(data['gradient_all'])} flags={data['gradient_all_flags']}")
 
 
+# single-branch trial evaluations (the optimiser's fast path): lnL(t), d lnL/dt, d2 lnL/dt2 by the reference's
+# upper-partial protocol (ref_driver branch mode) on four unscaled cases -- 4, 20 and 61 states, tip partials and tip states
+BRANCH_TRIAL_CASES = ("gtr_g4_t16", "gtr_g4_t24_gaps_tipstates", "wag_g4_t12", "mg94_t8")
+
+
+def run_branch_trials(name):
+    d = os.path.join(HERE, name)
+    out = os.path.join(d, "branch_trials.json")
+    subprocess.check_call([DRIVER, "branch", "spec.txt", out], cwd=d, stdout=subprocess.DEVNULL)
+    with open(out) as f:
+        data = json.load(f)
+    with open(out, "w") as f:
+        json.dump(data, f, separators=(",", ":"))
+    print(name, "branch trials:", len(data["trials"]))
+
+
 if __name__ == "__main__":
     build_ref()
     only = sys.argv[1:]
+    if only == ["branch_trials"]:
+        for name in BRANCH_TRIAL_CASES:
+            run_branch_trials(name)
+        sys.exit(0)
     for name, opts in CASES:
         if not only or name in only:
             run_case(name, opts)
+            if name in BRANCH_TRIAL_CASES:
+                run_branch_trials(name)
     if not only or "fluA_jc69_time" in only:
         run_fluA()
     if not only or "fluA_hky_g4_time" in only:

@@ -3,10 +3,12 @@
 Tolerances (SURVEY.md 8c): lnL 1e-10 relative; per-pattern lnL 1e-11 (+1e-11 abs); partials 1e-9 relative;
 gradient 1e-9 * max(1, |g|_inf).
 """
+import os
+
 import numpy as np
 import pytest
 
-from golden_util import UNROOTED_CASES, load, oracle_problem, read_spec
+from golden_util import GOLDEN, UNROOTED_CASES, load, oracle_problem, read_spec
 from gpu_util import engine_from_problem, random_problem
 from oracle import phyoracle as po
 from physher_amd.engine import GRAD_COMPAT_SCALED, GRAD_FOLD_ROOT_FREQS, RESCALE_ALWAYS, RESCALE_AUTO, RESCALE_NEVER, Engine, EngineError
@@ -748,16 +750,20 @@ def test_single_branch_updates_recompute_only_the_path_to_the_root(S, T, P, C, r
 @pytest.mark.parametrize("S,T,P,C,fold,rescale", [(4, 20, 333, 4, 0, 0), (4, 9, 64, 1, 0, 0), (4, 14, 100, 3, 1, 0), (4, 60, 150, 4, 0, 1), (4, 30, 70, 1, 0, 1),
                                                   (20, 12, 90, 2, 0, 0), (61, 8, 33, 1, 0, 0), (20, 50, 40, 2, 0, 1), (60, 7, 300, 1, 1, 0)])
 def test_single_branch_evaluation(S, T, P, C, fold, rescale):
-    """phyamd_branch_log_likelihood against full recomputations: lnL(t) for trial lengths of tip and internal branches,
-    d1 against the branch gradient and central differences, d2 against central differences of d1
+    """phyamd_branch_log_likelihood against the CPU oracle evaluated at the trial length: lnL(t) and d1 for trial lengths of tip
+    and internal branches; d2 against central differences of d1 (and against the reference's own d2lnldt2_uppper values in
+    test_single_branch_evaluation_matches_reference_fixture below)
     (_calculate_uppper / dlnldt_uppper / d2lnldt2_uppper, treelikelihood.c:2196-2335, 2592-2686).  Every state count;
     rescaled evaluations anchor the stored (scaled) partials on the per-pattern lnL they belong to."""
     pb = random_problem(T, P, C, seed=60 + T + S, S=S, gaps=0.03, fold_root_freqs=fold, bl=(0.3, 0.9) if rescale else (0.01, 0.1), rescale=rescale)
     flags = GRAD_FOLD_ROOT_FREQS if fold else 0
     mode = RESCALE_ALWAYS if rescale else RESCALE_NEVER
-    with engine_from_problem(pb, rescale=mode) as e, engine_from_problem(pb, rescale=mode) as full:
+    oracle0 = pb.gradient()
+    with engine_from_problem(pb, rescale=mode) as e:
         e.set_keep_partials(True)
         lnl0, cg = e.gradient(flags)
+        if not fold:
+            assert abs(lnl0 - oracle0["lnl"]) <= 1e-10 * abs(oracle0["lnl"])
         bg = po.branch_gradient_from_cat(cg, pb.cat_rates, pb.cat_props)
         rng = np.random.default_rng(1)
         nodes = [0, T - 1] + list(rng.choice([n for n in range(T, pb.N) if n != pb.root], size=3, replace=False))
@@ -769,11 +775,13 @@ def test_single_branch_evaluation(S, T, P, C, fold, rescale):
                 assert abs(d1 - bg[n]) <= 1e-9 * max(1.0, abs(bg).max())
             for t in (0.5 * t0, 1.7 * t0, 0.3):
                 lt, d1t, d2t = e.branch_log_likelihood(n, t)
-                if not fold:
-                    bl = pb.branch_lengths.copy()
-                    bl[n] = t
-                    full.set_branch_lengths(bl)
-                    assert abs(lt - full.log_likelihood()) <= 1e-11 * abs(lt)
+                if not fold:  # the CPU oracle evaluated at the trial length: lnL(t) and d lnL / dt
+                    pb.branch_lengths[n] = t
+                    o = pb.gradient()
+                    pb.branch_lengths[n] = t0
+                    assert abs(lt - o["lnl"]) <= 1e-10 * abs(lt), (n, t)
+                    o_d1 = po.branch_gradient_from_cat(o["cat_grad"], pb.cat_rates, pb.cat_props)[n]
+                    assert abs(d1t - o_d1) <= 1e-9 * max(1.0, np.abs(o["cat_grad"]).max()), (n, t)
                 h = 1e-5 * max(t, 1e-3)
                 lp, d1p, _ = e.branch_log_likelihood(n, t + h)
                 lm, d1m, _ = e.branch_log_likelihood(n, t - h)
@@ -788,32 +796,57 @@ def test_single_branch_evaluation_without_resident_uppers(S, T, P, C, rescale):
     """The optimiser's loop as the reference runs it (optimizer.c:116-150): for branch after branch, trial lengths, then the
     accepted length is set and the next branch follows.  No keep-partials gradient in between: the one upper partial a
     branch needs is rebuilt by a walk down its path from the root (fringe, DEEP and stored siblings alike), pending single-branch
-    changes recompute only their paths to the root.  Every value against a fresh full recomputation."""
+    changes recompute only their paths to the root.  Every value against the CPU oracle at the same lengths."""
     pb = random_problem(T, P, C, seed=90 + T + S, S=S, gaps=0.03, bl=(0.3, 0.9) if rescale else (0.01, 0.1), rescale=rescale)
     mode = RESCALE_ALWAYS if rescale else RESCALE_NEVER
     rng = np.random.default_rng(T)
-    with engine_from_problem(pb, rescale=mode) as e, engine_from_problem(pb, rescale=mode) as full:
+    with engine_from_problem(pb, rescale=mode) as e:
         bl = pb.branch_lengths.copy()
         order = [n for n in range(pb.N) if n != pb.root]
         rng.shuffle(order)
         for n in order[:12]:  # tips, cherries' tips, fringe and DEEP nodes, stored nodes: whatever the shuffle brings
             for t in (0.6 * bl[n], 1.5 * bl[n] + 0.01):
                 lt, d1, d2 = e.branch_log_likelihood(n, t)
-                trial = bl.copy()
-                trial[n] = t
-                full.set_branch_lengths(trial)
-                ref_lnl, ref_cg = full.gradient()
-                assert abs(lt - ref_lnl) <= 1e-11 * abs(ref_lnl), (n, t)
+                pb.branch_lengths[:] = bl
+                pb.branch_lengths[n] = t
+                o = pb.gradient()  # the CPU oracle at the trial length
+                ref_lnl, ref_cg = o["lnl"], o["cat_grad"]
+                assert abs(lt - ref_lnl) <= 1e-10 * abs(ref_lnl), (n, t)
                 ref_bg = po.branch_gradient_from_cat(ref_cg, pb.cat_rates, pb.cat_props)
                 assert abs(d1 - ref_bg[n]) <= 1e-9 * max(1.0, np.abs(ref_bg).max()), (n, t)
             bl[n] = 1.5 * bl[n] + 0.01  # accept the last trial: the next branch sees it
             e.set_branch_length(n, bl[n])
-        assert abs(e.log_likelihood() - ref_lnl) <= 1e-11 * abs(ref_lnl)
+        assert abs(e.log_likelihood() - ref_lnl) <= 1e-10 * abs(ref_lnl)
         e.set_profiling(True)
         n = order[20 % len(order)]
         e.branch_log_likelihood(n, bl[n])
         e.branch_log_likelihood(n, 1.1 * bl[n])  # same branch again: the rebuilt upper is reused, nothing is recomputed
         assert e.profile()["lower_launches"] == 0
+
+
+@pytest.mark.parametrize("case", ["gtr_g4_t16", "gtr_g4_t24_gaps_tipstates", "wag_g4_t12", "mg94_t8"])
+@pytest.mark.parametrize("resident", [False, True])
+def test_single_branch_evaluation_matches_reference_fixture(case, resident):
+    """lnL(t), d lnL/dt and d2 lnL/dt2 of single branches at trial lengths against values the compiled reference produced with
+    its own upper-partial protocol (full evaluation at the trial length, update_upper_partials, calculate_dldt_uppper,
+    d2lnldt2_uppper: treelikelihood.c:469-530, 2196-2335; fixtures tests/golden/<case>/branch_trials.json, written by
+    make_golden.py through `ref_driver branch`): 4, 20 and 61 states, tip partials and tip states, a tip, two inner branches
+    and a branch next to the root."""
+    import json
+    gold = load(case)
+    spec = read_spec(case)
+    with open(os.path.join(GOLDEN, case, "branch_trials.json")) as f:
+        trials = json.load(f)["trials"]
+    pb = oracle_problem(case, gold)
+    with engine_from_problem(pb, tip_mode="states" if spec["tipstates"] == "1" else "partials") as e:
+        if resident:
+            e.set_keep_partials(True)
+            e.gradient()
+        for tr in trials:
+            lnl, d1, d2 = e.branch_log_likelihood(tr["node"], tr["length"])
+            assert abs(lnl - tr["lnl"]) <= 1e-10 * abs(tr["lnl"]), tr
+            assert abs(d1 - tr["d1"]) <= 1e-8 * max(1.0, abs(tr["d1"])), (tr, d1)
+            assert abs(d2 - tr["d2"]) <= 1e-7 * max(1.0, abs(tr["d2"])), (tr, d2)
 
 
 @pytest.mark.parametrize("S,T,P,C", [(4, 30, 400, 4), (20, 10, 120, 2)])
@@ -860,48 +893,76 @@ def test_newton_branch_length_optimisation(S, T, P, C):
 # ---------------------------------------------------------------------------------------------------------
 # pattern tiling under a device-memory cap (SURVEY 8d "memory feasibility")
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("S,T,P,C,rescale", [(4, 40, 3000, 4, RESCALE_NEVER), (4, 30, 1000, 2, RESCALE_ALWAYS), (20, 12, 1500, 2, RESCALE_NEVER),
-                                             (61, 8, 700, 1, RESCALE_NEVER)])
-def test_pattern_tiling_under_a_memory_cap(S, T, P, C, rescale):
+@pytest.mark.parametrize("S,T,P,C,rescale,shape", [(4, 40, 3000, 4, RESCALE_NEVER, "random"), (4, 30, 3000, 2, RESCALE_ALWAYS, "random"),
+                                                   (4, 40, 3000, 4, RESCALE_NEVER, "caterpillar"), (20, 12, 1500, 2, RESCALE_NEVER, "random"),
+                                                   (20, 12, 1500, 2, RESCALE_NEVER, "caterpillar"), (61, 8, 2000, 1, RESCALE_NEVER, "random")])
+def test_pattern_tiling_under_a_memory_cap(S, T, P, C, rescale, shape):
     """max_device_bytes below the untiled working set: the engine walks the patterns in tiles through one set of partial
-    arrays and adds the per-tile sums in tile order.  lnL, per-pattern lnL, the gradient and the substitution-parameter sums
-    equal the untiled engine's (ragged last tile included); calls that need resident partials are refused."""
+    arrays and adds the per-tile sums in tile order.  lnL, per-pattern lnL and the gradient equal the ORACLE's (ragged last tile
+    included), the substitution-parameter sums the untiled engine's; the engine never holds more than the cap (the tile size
+    follows the real tree at phyamd_set_topology: a ladder-like tree stores twice what a random one does); calls that need
+    resident partials are refused."""
     forced = rescale == RESCALE_ALWAYS
-    pb = random_problem(T, P, C, seed=4000 + S + T, S=S, gaps=0.04, bl=(0.3, 0.9) if forced else (0.01, 0.1), rescale=1 if forced else 0)
+    pb = random_problem(T, P, C, seed=4000 + S + T, S=S, shape=shape, gaps=0.04, bl=(0.3, 0.9) if forced else (0.01, 0.1), rescale=1 if forced else 0)
+    ref = pb.gradient()
     rng = np.random.default_rng(S)
     dQ = rng.normal(size=(3, S, S))
     dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(S)[None]
-    per_pattern = 8.0 * C * S * ((0.5 if S == 4 else 1.6) * (T - 1) + 2.0) + T  # the engine's own estimate of its working set
-    cap = int(per_pattern * 600 + T * P + 16 * P)          # room for ~600 patterns at a time: tiles of 512
-    with engine_from_problem(pb, rescale=rescale) as whole, engine_from_problem(pb, rescale=rescale, max_device_bytes=cap) as e:
-        tiles = e.profile()["tiles"]
-        assert tiles == -(-P // 512) and whole.profile()["tiles"] == 1
-        assert e.profile()["device_bytes"] < whole.profile()["device_bytes"]
-        lnl = e.log_likelihood()
-        ref = whole.log_likelihood()
-        assert abs(lnl - ref) <= 1e-12 * abs(ref)
-        np.testing.assert_allclose(e.pattern_log_likelihoods(), whole.pattern_log_likelihoods(), rtol=1e-13, atol=1e-13)
-        l2, cg = e.gradient()
+    with engine_from_problem(pb, rescale=rescale) as whole:
         l3, cg_ref = whole.gradient()
-        assert abs(l2 - l3) <= 1e-12 * abs(l3)
-        assert np.abs(cg - cg_ref).max() <= 1e-10 * max(1.0, np.abs(cg_ref).max())
-        if C >= 2:  # the +I root term is summed over the tiles while each tile's root partial is resident
-            assert abs(e.root_invariant_term() - whole.root_invariant_term()) <= 1e-10 * max(1.0, abs(whole.root_invariant_term()))
-        e.set_rate_matrix_derivatives(dQ)
-        whole.set_rate_matrix_derivatives(dQ)
-        if S == 4 or not forced:
-            _, _, pg = e.parameter_gradient()
-            _, _, pg_ref = whole.parameter_gradient()
-            assert np.abs(pg - pg_ref).max() <= 1e-10 * max(1.0, np.abs(pg_ref).max())
-            np.testing.assert_allclose(e.root_frequency_term(), whole.root_frequency_term(), rtol=1e-11)
-        e.set_branch_length(0, 0.2)  # a changed branch: every tile is recomputed
-        whole.set_branch_length(0, 0.2)
-        assert abs(e.log_likelihood() - whole.log_likelihood()) <= 1e-12 * abs(ref)
-        for call in (lambda: e.partials(T), lambda: e.set_keep_partials(True), lambda: e.store(), lambda: e.branch_log_likelihood(0, 0.1)):
-            with pytest.raises(EngineError):
-                call()
+        untiled_bytes = whole.profile()["device_bytes"]
+        cap = int(0.45 * untiled_bytes)
+        with engine_from_problem(pb, rescale=rescale, max_device_bytes=cap) as e:
+            assert e.profile()["tiles"] >= 2 and whole.profile()["tiles"] == 1
+            lnl = e.log_likelihood()
+            assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+            np.testing.assert_allclose(e.pattern_log_likelihoods(), ref["pattern_lk"], rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(e.pattern_log_likelihoods(), whole.pattern_log_likelihoods(), rtol=1e-13, atol=1e-13)
+            l2, cg = e.gradient()
+            assert abs(l2 - l3) <= 1e-12 * abs(l3)
+            assert np.abs(cg - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+            assert np.abs(cg - cg_ref).max() <= 1e-10 * max(1.0, np.abs(cg_ref).max())
+            if C >= 2:  # the +I root term is summed over the tiles while each tile's root partial is resident
+                assert abs(e.root_invariant_term() - whole.root_invariant_term()) <= 1e-10 * max(1.0, abs(whole.root_invariant_term()))
+            e.set_rate_matrix_derivatives(dQ)
+            whole.set_rate_matrix_derivatives(dQ)
+            if S == 4:
+                _, _, pg = e.parameter_gradient()
+                _, _, pg_ref = whole.parameter_gradient()
+                assert np.abs(pg - pg_ref).max() <= 1e-10 * max(1.0, np.abs(pg_ref).max())
+                _, pg_oracle = po.parameter_gradient(pb, dQ)
+                assert np.abs(pg - pg_oracle).max() <= 1e-8 * max(1.0, np.abs(pg_oracle).max())
+                np.testing.assert_allclose(e.root_frequency_term(), po.root_frequency_term(pb), rtol=1e-9)
+            e.set_branch_length(0, 0.2)  # a changed branch: every tile is recomputed
+            pb.branch_lengths[0] = 0.2
+            assert abs(e.log_likelihood() - pb.log_likelihood()["lnl"]) <= 1e-10 * abs(ref["lnl"])
+            for call in (lambda: e.partials(T), lambda: e.set_keep_partials(True), lambda: e.store(), lambda: e.branch_log_likelihood(0, 0.1)):
+                with pytest.raises(EngineError):
+                    call()
+            assert e.profile()["device_bytes"] <= cap, (e.profile(), cap)  # the guarantee of max_device_bytes
     with pytest.raises(EngineError):
         Engine(T, P, S, C, max_device_bytes=1000)  # below the smallest tile
+
+
+def test_memory_cap_is_never_exceeded_by_later_requests():
+    """20 states, tiled: a substitution-parameter gradient wants every node's lower and upper partial resident (about three
+    times the tile's working set).  Under an explicit cap that is refused with PHYAMD_ENOMEM instead of silently overshooting."""
+    S, T, P, C = 20, 12, 1500, 2
+    pb = random_problem(T, P, C, seed=4100, S=S)
+    with engine_from_problem(pb) as whole:
+        whole.gradient()
+        cap = int(0.45 * whole.profile()["device_bytes"])
+    rng = np.random.default_rng(5)
+    dQ = rng.normal(size=(2, S, S))
+    dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(S)[None]
+    with engine_from_problem(pb, max_device_bytes=cap) as e:
+        e.gradient()
+        e.set_rate_matrix_derivatives(dQ)
+        try:
+            e.parameter_gradient()
+        except EngineError as err:
+            assert err.code == -3, err  # PHYAMD_ENOMEM
+        assert e.profile()["device_bytes"] <= cap
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -912,13 +973,13 @@ def test_pattern_tiling_under_a_memory_cap(S, T, P, C, rescale):
                                                   (61, 30, 20, 1, RESCALE_ALWAYS, False)])
 def test_store_restore_mcmc_walk(S, T, P, C, rescale, keep):
     """A short Metropolis-style walk: proposals change one branch, a few branches, every branch, or the category rates; each
-    is evaluated, then accepted (store) or rejected (restore).  Every evaluation equals a fresh full recomputation of the
-    same parameters; after a restore the stored lnL and gradient come back and only the root is re-integrated
+    is evaluated, then accepted (store) or rejected (restore).  Every evaluation equals the CPU ORACLE at the same
+    parameters; after a restore the stored lnL and gradient come back and only the root is re-integrated
     (_singleTreeLikelihood_store / _treelikelihood_handle_restore, treelikelihood.c:116-161)."""
     forced = rescale == RESCALE_ALWAYS
     pb = random_problem(T, P, C, seed=7000 + S + T, S=S, gaps=0.03, bl=(0.3, 0.9) if forced else (0.01, 0.1), rescale=1 if forced else 0)
     rng = np.random.default_rng(S + T)
-    with engine_from_problem(pb, rescale=rescale) as e, engine_from_problem(pb, rescale=rescale) as full:
+    with engine_from_problem(pb, rescale=rescale) as e:
         with pytest.raises(EngineError):
             e.restore()  # nothing stored yet
         if keep:
@@ -929,10 +990,10 @@ def test_store_restore_mcmc_walk(S, T, P, C, rescale, keep):
         e.store()
         non_root = [n for n in range(pb.N) if n != pb.root]
 
-        def reference(bl_, rates_):
-            full.set_category_rates(rates_, pb.cat_props)
-            full.set_branch_lengths(bl_)
-            return full.gradient()
+        def reference(bl_, rates_):  # the CPU oracle at these parameters (accepted and rejected states alike)
+            o = po.Problem(pb.left, pb.right, pb.root, pb.weights, pb.eval, pb.evec, pb.ivec, pb.freqs, rates_, pb.cat_props, bl_,
+                           tip_states=pb.tip_states, rescale=pb.rescale).gradient()
+            return o["lnl"], o["cat_grad"]
 
         accepted = rejected = 0
         for step in range(14):
@@ -954,10 +1015,10 @@ def test_store_restore_mcmc_walk(S, T, P, C, rescale, keep):
                 e.set_category_rates(nrates, pb.cat_props)
             lnl_new = e.log_likelihood()
             ref_lnl, ref_cg = reference(nbl, nrates)
-            assert abs(lnl_new - ref_lnl) <= 1e-12 * abs(ref_lnl), (step, kind)
+            assert abs(lnl_new - ref_lnl) <= 1e-10 * abs(ref_lnl), (step, kind)
             if step % 3 == 0:  # accept
                 _, cg = e.gradient()
-                assert np.abs(cg - ref_cg).max() <= 1e-10 * max(1.0, np.abs(ref_cg).max())
+                assert np.abs(cg - ref_cg).max() <= 1e-9 * max(1.0, np.abs(ref_cg).max())
                 bl, rates, lnl_cur = nbl, nrates, lnl_new
                 e.store()
                 accepted += 1
@@ -968,14 +1029,36 @@ def test_store_restore_mcmc_walk(S, T, P, C, rescale, keep):
                 assert e.profile()["lower_launches"] <= 1  # the root alone
                 ref_lnl, ref_cg = reference(bl, rates)
                 lnl_g, cg = e.gradient()
-                assert abs(lnl_g - ref_lnl) <= 1e-12 * abs(ref_lnl)
-                assert np.abs(cg - ref_cg).max() <= 1e-10 * max(1.0, np.abs(ref_cg).max())
+                assert abs(lnl_g - ref_lnl) <= 1e-10 * abs(ref_lnl)
+                assert np.abs(cg - ref_cg).max() <= 1e-9 * max(1.0, np.abs(ref_cg).max())
                 rejected += 1
         assert accepted >= 4 and rejected >= 8
         # data changes drop the stored state
         e.set_pattern_weights(pb.weights)
         with pytest.raises(EngineError):
             e.restore()
+
+
+@pytest.mark.parametrize("S,T,P,C", [(4, 40, 300, 4), (20, 10, 50, 2)])
+def test_store_after_the_partial_storage_has_shrunk(S, T, P, C):
+    """keep_partials on (every internal node stored) and off again (the fused schedule stores about a third of them, the
+    allocation is kept): the first phyamd_store must move only the live slots into its two-slot buffer."""
+    pb = random_problem(T, P, C, seed=7700 + S, S=S, gaps=0.02)
+    ref = pb.gradient()
+    with engine_from_problem(pb) as e:
+        e.set_keep_partials(True)
+        e.gradient()
+        e.set_keep_partials(False)
+        assert abs(e.log_likelihood() - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        e.store()
+        bl = pb.branch_lengths * 1.3
+        e.set_branch_lengths(bl)
+        pb2 = po.Problem(pb.left, pb.right, pb.root, pb.weights, pb.eval, pb.evec, pb.ivec, pb.freqs, pb.cat_rates, pb.cat_props, bl, tip_states=pb.tip_states)
+        assert abs(e.log_likelihood() - pb2.log_likelihood()["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        e.restore()
+        lnl, cg = e.gradient()
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        assert np.abs(cg - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
 
 
 def test_root_terms_agree_between_rescaled_and_unscaled_evaluations():

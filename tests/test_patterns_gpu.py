@@ -1,5 +1,7 @@
-"""GPU: site-pattern compression on the device (phyamd_compress_patterns) against the host library's
-sequential table, which is itself pinned byte for byte to the reference's new_SitePattern (tests/test_host_models.py).
+"""GPU: site-pattern compression on the device (phyamd_compress_patterns) against the ORACLE's sequential hash
+table (oracle/phyoracle.c::phyo_compress_patterns, pinned to the reference's new_SitePattern by tests/test_oracle_golden.py)
+and against the patterns / weights the compiled reference itself produced for every committed alignment (gold["patterns"],
+gold["weights"]).  The product's own host table is compared too, but is never the only yardstick.
 Bit-exact: the same columns, in the same order, with the same weights."""
 import ctypes as C
 import os
@@ -8,7 +10,8 @@ import time
 import numpy as np
 import pytest
 
-from golden_util import GOLDEN, UNROOTED_CASES, read_fasta, read_spec
+from golden_util import GOLDEN, UNROOTED_CASES, load, read_fasta, read_spec
+from oracle import phyoracle as po
 
 pytestmark = pytest.mark.gpu
 
@@ -32,9 +35,12 @@ def test_device_compression_is_bit_exact(T, L, alphabet, datatype):
     rng = np.random.default_rng(T * 1000 + L)
     seqs = _random_alignment(rng, T, L, alphabet)
     names = [f"t{i}" for i in range(T)]
-    hs, hw = pc.compress_patterns(datatype, names, seqs)
     ds, dw = pc.compress_patterns_device(datatype, names, seqs)
-    assert ds.shape == hs.shape
+    os_, ow = po.compress_patterns(po.encode_alignment(datatype, seqs))  # the oracle's chained table, column by column
+    assert ds.shape == os_.shape
+    np.testing.assert_array_equal(ds, os_)
+    np.testing.assert_array_equal(dw, ow)
+    hs, hw = pc.compress_patterns(datatype, names, seqs)  # and the host library's table agrees with both
     np.testing.assert_array_equal(ds, hs)
     np.testing.assert_array_equal(dw, hw)
     assert dw.sum() == L
@@ -47,10 +53,10 @@ def test_device_compression_codons_and_growth_boundaries():
     rng = np.random.default_rng(3)
     seqs = _random_alignment(rng, 5, 3 * 4000, "ACGT", p_dup=0.3)
     names = [f"t{i}" for i in range(5)]
-    hs, hw = pc.compress_patterns("codon", names, seqs)
+    os_, ow = po.compress_patterns(po.encode_alignment("codon", seqs))
     ds, dw = pc.compress_patterns_device("codon", names, seqs)
-    np.testing.assert_array_equal(ds, hs)
-    np.testing.assert_array_equal(dw, hw)
+    np.testing.assert_array_equal(ds, os_)
+    np.testing.assert_array_equal(dw, ow)
     T = 6
     cols = set()
     while len(cols) < 260:
@@ -61,24 +67,25 @@ def test_device_compression_codons_and_growth_boundaries():
         order = rng.permutation(n)
         picks = np.concatenate([order, rng.integers(0, n, size=50)])  # every column once, then repeats
         seqs = ["".join("ACGT"[c] for c in cols[t, picks]) for t in range(T)]
-        hs, hw = pc.compress_patterns("nucleotide", names, seqs)
+        os_, ow = po.compress_patterns(po.encode_alignment("nucleotide", seqs))
         ds, dw = pc.compress_patterns_device("nucleotide", names, seqs)
-        assert hs.shape[1] == n
-        np.testing.assert_array_equal(ds, hs)
-        np.testing.assert_array_equal(dw, hw)
+        assert os_.shape[1] == n
+        np.testing.assert_array_equal(ds, os_)
+        np.testing.assert_array_equal(dw, ow)
 
 
 def test_device_compression_golden_alignments():
-    """every committed alignment, including the reference's own fluA data"""
+    """every committed alignment, including the reference's own fluA data: the device's patterns and weights are the ones
+    the compiled reference's new_SitePattern produced (fixtures), byte for byte"""
     from physher_amd import _phycpp_amd as pc
     cases = [(c, os.path.join(GOLDEN, c, "aln.fa"), read_spec(c)["datatype"]) for c in UNROOTED_CASES]
-    cases.append(("fluA", os.path.join(GOLDEN, "fluA_jc69_time", "fluA.fa"), "nucleotide"))
+    cases.append(("fluA_jc69_time", os.path.join(GOLDEN, "fluA_jc69_time", "fluA.fa"), "nucleotide"))
     for case, path, datatype in cases:
         names, seqs = read_fasta(path)
-        hs, hw = pc.compress_patterns(datatype, names, seqs)
+        gold = load(case)
         ds, dw = pc.compress_patterns_device(datatype, names, seqs)
-        np.testing.assert_array_equal(ds, hs, err_msg=case)
-        np.testing.assert_array_equal(dw, hw, err_msg=case)
+        np.testing.assert_array_equal(ds, gold["patterns"], err_msg=case)
+        np.testing.assert_array_equal(dw, gold["weights"], err_msg=case)
 
 
 def test_c_abi_argument_checks():
