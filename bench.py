@@ -330,18 +330,33 @@ def main():
         launches = max(1, p["upper_launches"])
         # 4 states, unscaled: the tree-walk kernels (ONE launch per pass); otherwise one launch per tree level
         kern = ("4_walk" if launches == 1 and T > 2 else "4") if S == 4 else "_gen"
-        achieved = upper_b / (prof["upper_ms"] * 1e-3) / 1e9 if prof["upper_ms"] > 0 else None
-        traffic = None
+        upper_s = prof["upper_ms"] * 1e-3
+        three_pass = upper_b / upper_s / 1e9 if upper_s > 0 else None
+        # PMC figures of the same workload (profiles/collect.sh -> profiles/traffic_latest.json): HBM bytes and vector-ALU
+        # wave-instructions per launch of the dominant kernel.  They describe THIS shape only: another shape reports null.
+        traffic = valu_insts = None
+        pmc_source = None
         if os.path.exists(args.traffic_json):
             try:
                 with open(args.traffic_json) as f:
                     tj = json.load(f)
-                if S == 4 and tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C and tj.get("launches_per_eval") == launches:
+                if tj.get("states", 4) == S and tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C and tj.get("launches_per_eval") == launches:
                     traffic = tj["upper_bytes_per_launch"]
+                    valu_insts = tj.get("upper_valu_insts_per_launch")
+                    pmc_source = tj.get("tag")
             except Exception:
                 traffic = None
+        achieved = traffic * launches / upper_s / 1e9 if traffic is not None and upper_s > 0 else None
+        valu = None
+        if valu_insts is not None and upper_s > 0:
+            # a wave instruction occupies its SIMD's 16-lane vector ALU for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+            valu_s = valu_insts * launches * 4.0 / (1024 * 2.4e9)
+            valu = {"wave_instructions_per_launch": valu_insts, "busy_frac": valu_s / upper_s,
+                    "note": "VALU wave-instructions (PMC SQ_INSTS_VALU) x 4 cycles / (1024 SIMDs x 2.4 GHz) / kernel time"}
+        workload_label = f"{T}-taxon {wl['name'].split(' (')[0]} fp64, {P:.0e} site patterns".replace("e+0", "e").replace("e+", "e")
         out = {
-            "metric": "lnL+gradient evals/sec, 1000-taxon GTR+G4 fp64, 1e6 site patterns"
+            "metric": ("lnL+gradient evals/sec, 1000-taxon GTR+G4 fp64, 1e6 site patterns" if (args.config == "cfg5" and T == 1000 and P == 1_000_000 and C == 4)
+                       else f"lnL+gradient evals/sec, {workload_label} [NOT the headline shape]")
                       + (" [+ 9 substitution-parameter gradients per eval: NOT the headline metric]" if args.subst_gradient else ""),
             "value": value,
             "unit": "evals/s",
@@ -355,27 +370,31 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{wl['name']}, {T} taxa x {P} patterns x {S} states x {C} categories, unrooted, full recompute per eval "
-                                   f"(BASELINE configs[{int(args.config[3]) - 1}] shape; {Pl} patterns on this rank)",
+                                   f"(BASELINE configs[{int(args.config[3]) - 1}] shape; {Pl} patterns on this rank); "
+                                   f"patterns = sites evolved down the tree on the GPU with integer weights 1..3 standing in for multiplicities, "
+                                   f"NOT de-duplicated ({distinct_note})",
                        "taxa": T, "patterns": P, "categories": C, "states": S, "patterns_per_gpu": Pl, "lnL": lnl,
                        "rescaling": eng.rescaling, "device_bytes": p["device_bytes"], "tiles": p["tiles"]},
             "roofline": {"bound": "hbm", "kernel": f"k_upper{kern} (pre-order pass + fused branch gradient)",
+                         # achieved / frac: MEASURED HBM bytes of the launch (PMC, per the guide's FETCH_SIZE / WRITE_SIZE recipe)
+                         # over the live HIP-event time of the same kernel; null when no PMC file matches this shape
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         # real HBM rate of the same launches: PMC bytes (profiles/traffic_latest.json) / HIP-event time.  `achieved`
-                         # counts the reference's three-pass bytes, most of which this design never moves, hence frac > 1
-                         "hbm_measured": None if traffic is None or prof["upper_ms"] <= 0 else
-                                         {"GB/s": traffic * launches / (prof["upper_ms"] * 1e-3) / 1e9,
-                                          "frac_of_peak": traffic * launches / (prof["upper_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "note": "achieved = the reference's three-pass algorithmic bytes of the pre-order + gradient passes (SURVEY 8d) / kernel time; "
-                                 "the fused kernels move about a tenth of them (traffic = PMC bytes per launch), so frac exceeds 1; "
-                                 "hbm_measured is the real HBM rate of the same launches",
-                         "algorithmic_bytes_per_launch": upper_b / launches, "launches_per_eval": launches,
+                         "traffic": traffic, "pmc_profile": pmc_source,
+                         "valu": valu,
+                         # the reference's three-pass algorithmic bytes over the same time: the fused kernels move about
+                         # a tenth of them, so this ratio exceeds 1 and is NOT a fraction of any roof
+                         "vs_three_pass": None if three_pass is None else
+                                          {"GB/s": three_pass, "ratio_to_hbm_peak": three_pass / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": upper_b / launches},
+                         "launches_per_eval": launches,
                          "avg_launch_ms": prof["upper_ms"] / launches,
-                         "lower_kernel": {"kernel": f"k_lower{kern}" if p["lower_launches"] == 1 or S != 4 else "k_lower4", "achieved": lower_b / (prof["lower_ms"] * 1e-3) / 1e9 if prof["lower_ms"] > 0 else None,
+                         "lower_kernel": {"kernel": f"k_lower{kern}" if p["lower_launches"] == 1 or S != 4 else "k_lower4",
                                           "launches_per_eval": p["lower_launches"], "ms_per_eval": prof["lower_ms"]},
                          "ms_per_eval": {k: prof[k] for k in prof}},
         }
+        if traffic is not None and tj.get("lower_bytes_per_launch") and prof["lower_ms"] > 0 and p["lower_launches"] == tj.get("lower_launches_per_eval", 1):
+            lb = tj["lower_bytes_per_launch"] * p["lower_launches"] / (prof["lower_ms"] * 1e-3) / 1e9
+            out["roofline"]["lower_kernel"].update({"achieved": lb, "frac": lb / HBM_PEAK_GBS, "traffic": tj["lower_bytes_per_launch"]})
         if S != 4:  # the 20-/61-state contraction runs on the fp64 matrix cores: report that side of the roofline too
             fl = algorithmic_flops(T, Pl, C, S)
             tf = fl / ((prof["lower_ms"] + prof["upper_ms"]) * 1e-3) / 1e12 if prof["upper_ms"] > 0 else None
