@@ -71,22 +71,6 @@ def evolve_on_device(tree, site_count, seed, device, S=4):
     return torch.stack(seqs[: tree.tip_count])
 
 
-def reversible_eigen(S, seed):
-    """Eigen system of a seeded random reversible S-state model (stand-in for WAG / MG94: same shapes, same work)."""
-    rng = np.random.default_rng(seed)
-    pi = rng.dirichlet(np.full(S, 20.0))
-    r = rng.uniform(0.2, 3.0, size=(S, S))
-    r = 0.5 * (r + r.T)
-    Q = r * pi[None, :]
-    np.fill_diagonal(Q, 0.0)
-    np.fill_diagonal(Q, -Q.sum(axis=1))
-    Q /= -(pi * np.diag(Q)).sum()
-    d = np.sqrt(pi)
-    B = (d[:, None] * Q) / d[None, :]
-    w, V = np.linalg.eigh(0.5 * (B + B.T))
-    return pi, w, V / d[:, None], V.T * d[None, :]
-
-
 def algorithmic_flops(T, P, C, S):
     """lower / upper node 2S(2S-1)+S flops per (pattern, category), branch gradient S(2S-1)+2S."""
     return P * C * ((3 * T - 3) * (2 * S * (2 * S - 1) + S) + (2 * T - 2) * (S * (2 * S - 1) + 2 * S))
@@ -95,8 +79,8 @@ def algorithmic_flops(T, P, C, S):
 # BASELINE.json configs[1..4]; the headline metric is quoted on configs[4]'s shape, which fits one GPU (160 GB)
 WORKLOADS = {
     "cfg2": dict(taxa=500, patterns=100_000, states=4, categories=4, name="GTR+G4 DNA"),
-    "cfg3": dict(taxa=200, patterns=50_000, states=20, categories=4, name="20-state reversible model (WAG+G4 shape)"),
-    "cfg4": dict(taxa=100, patterns=20_000, states=61, categories=1, name="61-state reversible model (MG94 codon shape)"),
+    "cfg3": dict(taxa=200, patterns=50_000, states=20, categories=4, name="WAG+G4 amino-acid"),
+    "cfg4": dict(taxa=100, patterns=20_000, states=61, categories=1, name="MG94 codon"),
     "cfg5": dict(taxa=1000, patterns=1_000_000, states=4, categories=4, name="GTR+G4 DNA"),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X spec sheet (fp64 matrix = fp64 vector on CDNA4)
@@ -158,7 +142,8 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
                     print(f"[bench] concurrent CPU timing skipped ({exc})", file=sys.stderr)
                 return dict(kind="reference", cores=1, t_eval=t_eval, patterns=compressed, iters=iters, lnl_ms=r["lnl_ms_per_eval"], multi=multi,
                             sample=f"physher SSE path (oracle/_ref/ref_driver bench), {T} taxa x {compressed} patterns "
-                                   f"(first {sp} sites of the workload), {iters} gradient evals after 1 warm-up, scaled linearly to the full pattern count")
+                                   f"(first {sp} sites of the workload: a cache-resident sample, which flatters the CPU), {iters} gradient evals after 1 warm-up, "
+                                   f"scaled linearly to the full pattern count")
             except Exception as exc:  # fall through to the port, but say why
                 print(f"[bench] reference driver failed ({exc}); timing the CPU port instead", file=sys.stderr)
     from oracle import phyoracle as po
@@ -170,6 +155,91 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
     t_eval = time.perf_counter() - t0
     return dict(kind="port", cores=1, t_eval=t_eval, patterns=sp, iters=1, lnl_ms=None,
                 sample=f"scalar CPU port (oracle/phyoracle.c), {T} taxa x {sp} patterns, 1 evaluation, scaled linearly")
+
+
+def count_distinct_patterns(states):
+    """Number of distinct columns of the synthetic alignment, by the product's own device pattern compressor
+    (phyamd_compress_patterns: bit-exact with the reference's new_SitePattern).  None if it declines."""
+    import ctypes as C
+    from physher_amd import _lib
+    lib = _lib.load()
+    T, L = states.shape
+    rows = (C.c_void_p * T)(*[states.ctypes.data + t * states.strides[0] for t in range(T)])
+    n = C.c_int32()
+    out = np.empty((T, L), dtype=np.uint8)
+    w = np.empty(L, dtype=np.float64)
+    rc = lib.phyamd_compress_patterns(-1, T, L, rows, None, C.byref(n), out.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p))
+    return int(n.value) if rc == 0 else None
+
+
+def named_model(config, seed):
+    """(frequencies, eval, evec, ivec, label) of the model BASELINE.json names for a configuration, from the host model library."""
+    from physher_amd import _phycpp_amd as pc
+    if config in ("cfg2", "cfg5"):
+        ev, U, Ui = gtr_eigen()
+        return np.array(GTR_FREQS), ev, U, Ui, "GTR"
+    if config == "cfg3":  # WAG with its own equilibrium frequencies (wag.c:38-44)
+        m = pc.substitution_model("WAG")
+        return m["frequencies"], m["eval"], m["evec"], m["ivec"], "WAG"
+    m = pc.substitution_model("MG94", [2.0, 1.0, 0.5])  # SURVEY 8d: kappa 2, alpha 1, beta 0.5, uniform codon frequencies
+    return m["frequencies"], m["eval"], m["evec"], m["ivec"], "MG94"
+
+
+def category_rates(C):
+    if C == 4:
+        r = np.array(GAMMA4_RATES_05)
+    else:
+        r = np.linspace(0.2, 1.8, C) if C > 1 else np.ones(1)
+    return r / r.mean(), np.full(C, 1.0 / C)
+
+
+def time_other_config(config, device, stream, seed, evals):
+    """One of BASELINE.json's smaller configurations (cfg2..cfg4) on the same GPU: ms per lnL + gradient evaluation with full
+    recompute, timed around synchronous calls (result on the host), plus the engine's HIP-event split."""
+    import torch
+    from physher_amd import synth
+    from physher_amd.engine import RESCALE_AUTO, Engine
+    wl = WORKLOADS[config]
+    T, P, C, S = wl["taxa"], wl["patterns"], wl["categories"], wl["states"]
+    tree = synth.random_tree(T, np.random.default_rng(seed))
+    states = np.ascontiguousarray(evolve_on_device(tree, P, seed * 100003, device, S).cpu().numpy())
+    weights = np.random.default_rng(seed + 17).integers(1, 4, size=P).astype(np.float64)
+    freqs, ev, U, Ui, model = named_model(config, seed)
+    rates, props = category_rates(C)
+    eng = Engine(T, P, S, C, device=device.index, rescale=RESCALE_AUTO, stream=stream.cuda_stream)
+    eng.set_topology(tree.left, tree.right, tree.root)
+    eng.set_branch_lengths(tree.length)
+    eng.set_eigen(ev, U, Ui)
+    eng.set_frequencies(freqs)
+    eng.set_category_rates(rates, props)
+    eng.set_pattern_weights(weights)
+    for t in range(T):
+        eng.set_tip_states(t, states[t])
+    eng.set_profiling(True)
+    for _ in range(2):
+        eng.set_branch_lengths(tree.length)
+        lnl, _ = eng.gradient()
+    torch.cuda.synchronize(device)
+    lower = upper = 0.0
+    t0 = time.perf_counter()
+    for _ in range(evals):
+        eng.set_branch_lengths(tree.length)  # full recompute (benchmarking.c:498-500)
+        lnl, _ = eng.gradient()
+        pr = eng.profile()
+        lower += pr["lower_ms"]
+        upper += pr["upper_ms"]
+    dt = (time.perf_counter() - t0) / evals
+    out = {"workload": f"{model}+G{C} ({wl['name']}), {T} taxa x {P} patterns x {S} states x {C} categories (BASELINE configs[{int(config[3]) - 1}])",
+           "evals_per_s": 1.0 / dt, "ms_per_eval": 1e3 * dt, "lower_ms": lower / evals, "upper_ms": upper / evals, "lnL": lnl,
+           "rescaling": eng.rescaling, "evals": evals}
+    if S != 4:
+        fl = algorithmic_flops(T, P, C, S)
+        tf = fl / ((lower + upper) / evals * 1e-3) / 1e12
+        out["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": fl}
+    eng.close()
+    del states
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -185,6 +255,8 @@ def main():
     ap.add_argument("--cpu-sample-patterns", type=int, default=8000)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg2..cfg4 and lnL-only secondary measurements (N = 1 only)")
+    ap.add_argument("--no-distinct-check", action="store_true", help="skip counting the distinct columns of the synthetic alignment")
     ap.add_argument("--rescale", choices=("auto", "always", "never"), default="auto",
                     help="rescaling policy (auto = the reference's lazy switch; always: NOT the headline configuration, measures the rescaled kernels)")
     ap.add_argument("--max-device-gb", type=float, default=0.0,
@@ -247,18 +319,12 @@ def main():
     wrng = np.random.default_rng(args.seed + 17)
     weights_all = wrng.integers(1, 4, size=P).astype(np.float64)
     weights = weights_all[lo:hi]
-    if C == 4:
-        cat_rates = np.array(GAMMA4_RATES_05)
-        cat_rates = cat_rates / cat_rates.mean()
-    else:
-        cat_rates = np.linspace(0.2, 1.8, C) if C > 1 else np.ones(1)
-        cat_rates = cat_rates / cat_rates.mean()
-    cat_props = np.full(C, 1.0 / C)
-    if S == 4:
-        freqs = np.array(GTR_FREQS)
-        ev, U, Ui = gtr_eigen()
-    else:
-        freqs, ev, U, Ui = reversible_eigen(S, args.seed)
+    cat_rates, cat_props = category_rates(C)
+    freqs, ev, U, Ui, model_name = named_model(args.config, args.seed)
+    distinct_note = "distinctness not checked on this rank"
+    if world == 1 and not args.no_distinct_check:
+        nd = count_distinct_patterns(states)
+        distinct_note = "device pattern compressor declined: not checked" if nd is None else f"{nd} of the {P} sites are distinct columns"
 
     # ONE stream for the engine's kernels and for everything torch does with their output (device-to-host copies, the
     # RCCL all-reduce): torch's default stream has handle 0, which the engine would take as "create your own stream", and a
@@ -415,6 +481,26 @@ def main():
                 out["cpu_baseline"]["all_cores"] = {"value": m["patterns_per_second"] / P, "unit": "evals/s", "cores": m["cores"],
                                                     "sample": f"{m['cores']} concurrent single-thread instances of the same sample, {m['iters']} gradient evals each; "
                                                               f"aggregate pattern throughput scaled to the full pattern count"}
+        if (world == 1 and not args.no_other_configs and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1
+                and not args.subst_gradient):
+            # SURVEY 8d secondary metric (examples/benchmarking.c:466-471): lnL only, full recompute, result on the host
+            evals = max(3, args.steps)
+            for _ in range(2):
+                eng.set_branch_lengths(tree.length)
+                eng.log_likelihood()
+            t1 = time.perf_counter()
+            for _ in range(evals):
+                eng.set_branch_lengths(tree.length)
+                lnl_only = eng.log_likelihood()
+            dt = (time.perf_counter() - t1) / evals
+            out["lnl_only"] = {"evals_per_s": 1.0 / dt, "ms_per_eval": 1e3 * dt, "lnL": lnl_only, "evals": evals,
+                               "note": "post-order pass + root integration only, same workload and protocol"}
+            out["other_configs"] = []
+            for cfg in ("cfg2", "cfg3", "cfg4"):
+                try:
+                    out["other_configs"].append(time_other_config(cfg, device, stream, args.seed, 10))
+                except Exception as exc:  # a secondary measurement must not lose the headline line
+                    out["other_configs"].append({"workload": cfg, "error": str(exc)})
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -11,6 +11,17 @@ namespace phyamd {
 // substitution models
 // ---------------------------------------------------------------------------------------------
 
+namespace {
+#include "aa_models.inc"
+
+// the universal genetic code over the 64 triplets in the order AAA, AAC, AAG, AAT, ACA, ... (A < C < G < T, first position
+// slowest): one letter per amino acid, '*' = stop.  The 61 sense codons, in this order, are the states of a codon model
+// (sitepattern.c:808-819, geneticcode.h).
+const char UNIVERSAL_CODE[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+}  // namespace
+
+const double *wag_frequencies() { return WAG_FREQUENCIES; }
+
 void build_symmetric_rates(const SubstModel &m, std::vector<double> &R) {
 	const int S = m.S;
 	R.assign((size_t)S * S, 0.0);
@@ -29,6 +40,33 @@ void build_symmetric_rates(const SubstModel &m, std::vector<double> &R) {
 			for (int j = i + 1; j < 4; j++) {
 				set(i, j, idx < (int)m.rates.size() ? m.rates[idx] : 1.0);
 				idx++;
+			}
+	} else if (m.name == "WAG" || m.name == "LG") {  // _wag_update_Q / _lg_update_Q (wag.c:23-36, lg.c:23-36): tabulated exchangeabilities
+		if (S != 20) throw Error(m.name + " is a 20-state model");
+		const double *tab = m.name == "WAG" ? WAG_EXCHANGEABILITIES : LG_EXCHANGEABILITIES;
+		size_t t = 0;
+		for (int i = 0; i < 20; i++)
+			for (int j = i + 1; j < 20; j++) set(i, j, tab[t++]);
+	} else if (m.name == "MG94") {
+		// _mg_update_Q (mg94.c:62-138): sense codons that differ at exactly one position exchange at
+		// (kappa if that difference is a transition) x (alpha if synonymous, beta if not); rates = {kappa, alpha, beta}
+		if (S != 61 || m.rates.size() != 3) throw Error("MG94 needs 61 states (universal code) and the rates kappa, alpha, beta");
+		const double kappa = m.rates[0], alpha = m.rates[1], beta = m.rates[2];
+		int sense[61], n = 0;
+		for (int x = 0; x < 64; x++)
+			if (UNIVERSAL_CODE[x] != '*') sense[n++] = x;
+		for (int i = 0; i < 61; i++)
+			for (int j = i + 1; j < 61; j++) {
+				const int a = sense[i], b = sense[j];
+				int differing = 0, na = 0, nb = 0;
+				for (int pos = 0; pos < 3; pos++) {
+					const int xa = (a >> (2 * (2 - pos))) & 3, xb = (b >> (2 * (2 - pos))) & 3;
+					if (xa != xb) differing++, na = xa, nb = xb;
+				}
+				if (differing != 1) continue;
+				const bool transition = (na ^ nb) == 2;  // A(0) <-> G(2), C(1) <-> T(3)
+				const bool synonymous = UNIVERSAL_CODE[a] == UNIVERSAL_CODE[b];
+				set(i, j, (transition ? kappa : 1.0) * (synonymous ? alpha : beta));
 			}
 	} else if (m.name == "GENERAL") {
 		// structure maps each pair of states to a rate index.  Layouts: S(S-1)/2 = the upper triangle row by row (the packed

@@ -107,12 +107,16 @@ struct SubstModel {
 	void p_t(double t, double *P, bool derivative = false);  // host reference of M1/M2, used by tests
 	// Differentiable parameters in the reference's order and its constrained-value convention (grad_wrt_reparam = false,
 	// treelikelihood.c:296-305): the rates as stored, then every frequency as a free coordinate.
-	int rate_parameter_count() const { return name == "JC69" ? 0 : (int)rates.size(); }
+	int rate_parameter_count() const { return (name == "JC69" || name == "WAG" || name == "LG") ? 0 : (int)rates.size(); }
 	// d(normalised Q)/d(parameter), [count][S][S]: _gtr_dQdp / _hky_dQdp / _general_dQdp (gtr.c:256-326, hky.c:493-541,
 	// gensubst.c:216-279) in one rule: dQ^ = dR o pi + R o dpi (rows re-zeroed), dQ = (dQ^ - Q dnorm) / norm
 	void rate_matrix_derivatives(bool want_rates, bool want_freqs, std::vector<double> &dQ);
 };
 void build_symmetric_rates(const SubstModel &m, std::vector<double> &R);  // exchangeabilities r_ij (i < j), row-major full matrix
+// model names: JC69, HKY, GTR, GENERAL (above) and the fixed-exchangeability models of the 20- and 61-state configurations:
+//   WAG, LG  (wag.c:23-36, lg.c:23-36): tabulated exchangeabilities, any frequencies (wag_frequencies() = WAG's own)
+//   MG94     (mg94.c:62-138): universal code, rates = {kappa, alpha, beta}, 61 codon frequencies
+const double *wag_frequencies();  // [20]
 
 // ---------------------------------------------------------------------------------------------
 // Site models (reference: sitemodel.c, gamma.c)

@@ -222,6 +222,27 @@ PYBIND11_MODULE(_phycpp_amd, m) {
 		phyamd::Patterns p = phyamd::compress_patterns_device(dt, names, seqs);
 		return py::make_tuple(py::array_t<unsigned char>({(py::ssize_t)p.taxon_count, (py::ssize_t)p.pattern_count}, p.states.data()), vec(p.weights));
 	});
+	// host substitution models by name (JC69, HKY, GTR, WAG, LG, MG94): normalised Q and its eigen system, as uploaded with
+	// phyamd_set_eigen / phyamd_set_frequencies.  frequencies = None: the model's own (WAG) or uniform.
+	m.def("substitution_model", [](const std::string &name, const std::vector<double> &rates, std::optional<std::vector<double>> frequencies) {
+		phyamd::SubstModel sm;
+		sm.name = name;
+		sm.S = (name == "WAG" || name == "LG") ? 20 : name == "MG94" ? 61 : 4;
+		sm.rates = rates;
+		if (frequencies) sm.freqs = *frequencies;
+		else if (name == "WAG") sm.freqs.assign(phyamd::wag_frequencies(), phyamd::wag_frequencies() + 20);
+		else sm.freqs.assign(sm.S, 1.0 / sm.S);
+		sm.update();
+		const ssize_t S = sm.S;
+		py::dict d;
+		d["state_count"] = sm.S;
+		d["frequencies"] = vec(sm.freqs);
+		d["Q"] = darray({S, S}, sm.Q.data());
+		d["eval"] = vec(sm.eval);
+		d["evec"] = darray({S, S}, sm.evec.data());
+		d["ivec"] = darray({S, S}, sm.ivec.data());
+		return d;
+	}, py::arg("name"), py::arg("rates") = std::vector<double>(), py::arg("frequencies") = std::nullopt);
 	m.def("gamma_quantile", &phyamd::gamma_quantile);
 	m.def("reg_lower_gamma", &phyamd::reg_lower_gamma);
 }

@@ -1,11 +1,13 @@
 #!/bin/bash
-# profiles/collect.sh TAG -- the three rocprofv3 passes behind bench.py's roofline object, run on the GPU box:
+# profiles/collect.sh TAG -- the rocprofv3 passes behind bench.py's roofline object, run on the GPU box:
 #   1. --kernel-trace --stats      : per-kernel durations (must agree with bench.py's HIP-event figures)
 #   2. --pmc FETCH_SIZE            : HBM read traffic of the two hot kernels   (own pass, kernel trace only)
 #   3. --pmc WRITE_SIZE            : HBM write traffic                           (own pass)
-# Raw output goes to /tmp on the box; only the small filtered summaries are copied to gpurun_out/prof_TAG/
-# (copy what is to be judged from there into profiles/).  Usage on the box, from the repo root:
-#   bash profiles/collect.sh r01c
+#   4. --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS : instruction mix (own pass)
+#   5. --pmc VALUBusy SALUBusy MemUnitBusy MemUnitStalled / SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+# Raw output goes to /tmp on the box; the small filtered summaries land in gpurun_out/prof_TAG/, together with TAG_traffic.json
+# (per-launch HBM bytes and VALU wave-instructions: copy it to profiles/traffic_latest.json for bench.py's roofline object) --
+# copy what is to be judged from there into profiles/.  Usage on the box, from the repo root:   bash profiles/collect.sh r02a
 set -eo pipefail
 TAG=${1:?tag}
 ROOT=$(pwd)
@@ -13,7 +15,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export PHYAMD_BENCH_BLOCK=1000000   # one generator block: fewer unrelated kernels in the trace
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs --no-distinct-check"
 KREGEX='k_(lower4|upper4|lower_gen|upper_gen)'
 
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- $BENCH --steps 4 --warmup 1 > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/kt.err"
@@ -22,17 +24,23 @@ head -1 "$f" > "$OUT/${TAG}_kernel_stats.csv"
 grep -E 'k_lower|k_upper|k_reduce_rows|k_transition|k_tip_tables|k_root' "$f" >> "$OUT/${TAG}_kernel_stats.csv" || true
 f=$(find /tmp/prof_kt -name 'kt_kernel_trace.csv' | head -1)
 head -1 "$f" > "$OUT/${TAG}_kernel_trace_phyamd.csv"
-grep -E 'k_lower|k_upper|k_reduce_rows|k_transition|k_tip_tables|k_root' "$f" | tail -200 >> "$OUT/${TAG}_kernel_trace_phyamd.csv" || true
+grep -E 'k_lower|k_upper|k_reduce_rows|k_transition|k_tip_tables|k_root' "$f" | tail -30 >> "$OUT/${TAG}_kernel_trace_phyamd.csv" || true
 echo "kernel trace done" >&2
 
-for ctr in FETCH_SIZE WRITE_SIZE; do
-	rocprofv3 --pmc $ctr --kernel-trace --output-format csv --kernel-include-regex "$KREGEX" -d /tmp/prof_$ctr -o pmc -- $BENCH --steps 1 --warmup 1 > /dev/null 2> "$OUT/pmc_$ctr.err"
-	f=$(find /tmp/prof_$ctr -name 'pmc_counter_collection.csv' | head -1)
-	head -1 "$f" > "$OUT/${TAG}_pmc_$ctr.csv"
-	grep -E "$KREGEX" "$f" | tail -8 >> "$OUT/${TAG}_pmc_$ctr.csv"
-	echo "$ctr done" >&2
+pass=0
+for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" "VALUBusy SALUBusy MemUnitBusy MemUnitStalled" \
+            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+	pass=$((pass + 1))
+	name=$(echo $ctrs | cut -d' ' -f1)
+	rocprofv3 --pmc $ctrs --kernel-trace --output-format csv --kernel-include-regex "$KREGEX" -d /tmp/prof_p$pass -o pmc -- $BENCH --steps 1 --warmup 1 > /dev/null 2> "$OUT/pmc_$name.err"
+	f=$(find /tmp/prof_p$pass -name 'pmc_counter_collection.csv' | head -1)
+	head -1 "$f" > "$OUT/${TAG}_pmc_$name.csv"
+	grep -E "$KREGEX" "$f" | tail -16 >> "$OUT/${TAG}_pmc_$name.csv"
+	echo "$name done" >&2
 done
 cd "$ROOT"
+python3 profiles/pmc_traffic.py "$TAG" "$OUT/${TAG}_pmc_FETCH_SIZE.csv" "$OUT/${TAG}_pmc_WRITE_SIZE.csv" 1000 1000000 4 1 "$OUT/${TAG}_traffic.json" "$OUT/${TAG}_pmc_SQ_INSTS_VALU.csv" > /dev/null
+cp "$OUT/${TAG}_traffic.json" profiles/traffic_latest.json   # (on the box: so that the bench line below carries the measured roofline)
 unset PHYAMD_BENCH_BLOCK
 python3 bench.py --steps 5 --warmup 2 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 ls -la "$OUT" >&2

@@ -1,35 +1,46 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) into per-launch HBM bytes.
+"""Turn rocprofv3 --pmc passes (separate runs, kernel trace only) into per-launch figures of the two tree-walk kernels:
+HBM bytes from FETCH_SIZE / WRITE_SIZE and, optionally, vector-ALU wave-instructions from SQ_INSTS_VALU.
 
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counter values are KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a 16-B-per-lane coalesced stream, so it is doubled; WRITE_SIZE
 is exact for 16-B-per-lane stores.  Only the launches of the LAST evaluation in the trace are used.
 
-usage: pmc_traffic.py FETCH.csv WRITE.csv taxa patterns categories launches_per_eval out.json
+usage: pmc_traffic.py TAG FETCH.csv WRITE.csv taxa patterns categories launches_per_eval out.json [BUSY.csv]
 """
 import csv
 import json
 import sys
 
 
-def per_kernel(fn, key, launches):
-    rows = [r for r in csv.DictReader(open(fn)) if key in r["Kernel_Name"]]
+def per_kernel(fn, key, launches, counter=None):
+    rows = [r for r in csv.DictReader(open(fn)) if key in r["Kernel_Name"] and (counter is None or r["Counter_Name"] == counter)]
     rows = rows[-launches:]
-    return sum(float(r["Counter_Value"]) for r in rows) * 1024.0, len(rows)
+    return sum(float(r["Counter_Value"]) for r in rows), len(rows)
 
 
 def main():
-    fetch, write, T, P, C, L, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
-    res = {"taxa": T, "patterns": P, "categories": C, "launches_per_eval": L, "source": [fetch, write],
-           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction)"}
+    tag, fetch, write = sys.argv[1], sys.argv[2], sys.argv[3]
+    T, P, C, L, out = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), sys.argv[8]
+    busy = sys.argv[9] if len(sys.argv) > 9 else None
+    res = {"tag": tag, "taxa": T, "patterns": P, "categories": C, "states": 4, "launches_per_eval": L, "lower_launches_per_eval": L, "source": [fetch, write] + ([busy] if busy else []),
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction); "
+                     "VALU = SQ_INSTS_VALU (wave-instructions) of the same launches in a third pass"}
     for name, key in (("upper", "k_upper4"), ("lower", "k_lower4")):
         f, n1 = per_kernel(fetch, key, L)
         w, n2 = per_kernel(write, key, L)
         assert n1 == n2 == L, (n1, n2, L)
+        f *= 1024.0
+        w *= 1024.0
         res[f"{name}_fetch_bytes_raw_per_eval"] = f
         res[f"{name}_write_bytes_per_eval"] = w
         res[f"{name}_bytes_per_eval"] = 2 * f + w
         res[f"{name}_bytes_per_launch"] = (2 * f + w) / L
+        if busy:
+            for ctr in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS"):
+                v, n3 = per_kernel(busy, key, L, ctr)
+                if n3 == L:
+                    res[f"{name}_{ctr[9:].lower()}_insts_per_launch"] = v / L
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

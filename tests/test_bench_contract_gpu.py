@@ -31,7 +31,12 @@ def test_bench_line_contract():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # achieved / frac are MEASURED HBM bytes (PMC) over the live kernel time: only present when profiles/traffic_latest.json
+    # describes this very shape -- never for this tiny workload; the three-pass ratio has its own name and is not a fraction
+    assert r["achieved"] is None and r["frac"] is None and r["traffic"] is None
+    assert r["vs_three_pass"]["GB/s"] > 0 and "valu" in r
+    assert "NOT the headline shape" in d["metric"] and "NOT de-duplicated" in d["config"]["workload"]
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

@@ -89,7 +89,7 @@ def test_transition_matrices_from_model_parameters(case):
     gold = load(case)
     spec = read_spec(case)
     m = _model_from_spec(spec, gold)
-    for q, node in enumerate(gold["pt_nodes"]):
+    for q, node in enumerate(gold["pt_nodes"] if "pt" in gold else []):  # (the slim rescaled fixtures carry no matrices)
         for c in range(gold["category_count"]):
             t = gold["distance"][node] * gold["cat_rates"][c]
             np.testing.assert_allclose(m.transition_matrix(t), gold["pt"][q, c], rtol=1e-11, atol=1e-14)
@@ -216,3 +216,53 @@ def test_clock_models():
     pc.SimpleClockModelInterface(rates, tm)
     with pytest.raises(pc.PhyamdError):
         pc.SimpleClockModelInterface(rates[:-1], tm)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# M3: the fixed-exchangeability models of the 20- and 61-state configurations (wag.c:23-36, lg.c:23-36, mg94.c:62-138)
+# ---------------------------------------------------------------------------------------------------------
+def _spec_model(case):
+    spec = read_spec(case)
+    name = {"wag": "WAG", "lg": "LG", "mg94": "MG94"}[spec["model"]]
+    rates = [float(x) for x in spec["rates"].split(",")] if "rates" in spec else []
+    freqs = [float(x) for x in spec["freqs"].split(",")] if "freqs" in spec else None
+    return name, rates, freqs
+
+
+@pytest.mark.parametrize("case", [c for c in UNROOTED_CASES if read_spec(c)["model"] in ("wag", "lg", "mg94")])
+def test_empirical_and_codon_rate_matrices_match_reference(case):
+    """WAG / LG exchangeability tables and the MG94 codon rule (universal code; kappa, alpha, beta) against the normalised Q,
+    the frequencies and P(t) of three branches that the compiled reference produced for the same model."""
+    gold = load(case)
+    name, rates, freqs = _spec_model(case)
+    if name == "MG94" and freqs is None:
+        freqs = list(gold["frequencies"])  # new_MG94_with_values starts from a uniform 61-simplex
+    m = pc.substitution_model(name, rates, freqs)
+    S = gold["state_count"]
+    assert m["state_count"] == S
+    np.testing.assert_allclose(m["frequencies"], gold["frequencies"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(m["Q"], gold["Q"], rtol=1e-12, atol=1e-15)
+    # the eigen system is a different basis (symmetrised Jacobi here, orthes + hqr2 there): compare what it is used for
+    Q = m["evec"] @ np.diag(m["eval"]) @ m["ivec"]
+    np.testing.assert_allclose(Q, gold["Q"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m["evec"] @ m["ivec"], np.eye(S), atol=1e-12)
+    for q, node in enumerate(gold["pt_nodes"] if "pt" in gold else []):  # (the slim rescaled fixtures carry no matrices)
+        for c in range(gold["category_count"]):
+            t = gold["distance"][node] * gold["cat_rates"][c]
+            P = np.abs(m["evec"] @ np.diag(np.exp(m["eval"] * t)) @ m["ivec"])  # substmodel.c:518-557
+            np.testing.assert_allclose(P, gold["pt"][q][c], rtol=1e-9, atol=1e-14)
+
+
+def test_wag_default_frequencies_and_mg94_structure():
+    m = pc.substitution_model("WAG")
+    assert abs(m["frequencies"].sum() - 1.0) < 1e-12 and m["Q"].shape == (20, 20)
+    np.testing.assert_allclose(m["Q"].sum(axis=1), 0.0, atol=1e-14)
+    assert abs(-(m["frequencies"] * np.diag(m["Q"])).sum() - 1.0) < 1e-13  # one expected substitution per unit time
+    mg = pc.substitution_model("MG94", [2.0, 1.0, 0.5])
+    Q = mg["Q"]
+    assert Q.shape == (61, 61)
+    # every sense codon has 9 single-nucleotide neighbours minus those that are stops: between 7 and 9 non-zero rates per row
+    nz = (Q != 0).sum(axis=1) - 1
+    assert nz.min() >= 7 and nz.max() == 9 and nz.sum() == 2 * 263  # 263 sense-codon pairs one substitution apart (universal code)
+    with pytest.raises(Exception):
+        pc.substitution_model("MG94", [2.0, 1.0])
