@@ -1,7 +1,7 @@
 // phyamd_engine.hip -- MI355X (gfx950) tree-likelihood engine behind include/physher_amd.h.
 //
 // One translation unit, assembled from:
-//   phyamd_device.inc / _level4 / _walk4 / _walk4c / _general / _patterns   device code (kernels)
+//   phyamd_device.inc / _level4 / _walk4 / _general / _patterns   device code (kernels)
 //   phyamd_shard.inc        state of one engine on one GPU (= one shard of the site patterns)
 //   phyamd_schedule.inc     level and tree-walk schedules, device storage
 //   phyamd_launch.inc       kernel launches per pass
@@ -104,12 +104,15 @@ struct NodeOp {
 	int32_t carry_in;   // lower walk: 1 / 2 = the left / right child's partial is the previous op's result;
 	                    // upper walk: 1 = the parent's upper is the previous op's carried child upper
 	int32_t carry_out;  // upper walk: 1 / 2 = the left / right child's upper goes to the next op in registers (not stored)
+	// upper walk, plain kernel: a parked upper whose waiting time holds no other park ("leaf park": two thirds of them in a random
+	// tree) can wait in the wave's LDS slot instead of HBM.  bit 0: the parent's upper is read from LDS; bit 1 / 2: the left /
+	// right child's upper is parked in LDS.  The HBM slot stays assigned (the rescaling and parameter variants use it).
+	int32_t lds_park;
 };
 
 #include "phyamd_device.inc"
 #include "phyamd_level4.inc"
 #include "phyamd_walk4.inc"
-#include "phyamd_walk4c.inc"
 #include "phyamd_general.inc"
 #include "phyamd_patterns.inc"
 
