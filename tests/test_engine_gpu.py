@@ -824,6 +824,50 @@ def test_single_branch_evaluation_without_resident_uppers(S, T, P, C, rescale):
         assert e.profile()["lower_launches"] == 0
 
 
+def test_fused_cherries_at_20_states(monkeypatch):
+    """20 states: cherries are fused into their parents' ops (never stored; their uppers stay in registers).  The fused schedule
+    and the one that stores every node (PHYAMD_GEN_FUSION=0) must both equal the CPU oracle -- lnL, per-pattern lnL, gradient --
+    and the single-branch evaluation must work on a cherry, on its tips and beside it (the cherry's partial is then formed on the
+    side); a one-branch change under a cherry recomputes through its first stored ancestor."""
+    pb = random_problem(40, 150, 3, seed=321, S=20, gaps=0.05)
+    o = pb.gradient()
+    cherries = [n for n in range(pb.T, pb.N) if pb.left[n] < pb.T and pb.right[n] < pb.T and n != pb.root]
+    assert len(cherries) >= 5
+    parent = np.full(pb.N, -1)
+    for n in range(pb.T, pb.N):
+        parent[pb.left[n]] = parent[pb.right[n]] = n
+    results = {}
+    for fusion in ("1", "0"):
+        monkeypatch.setenv("PHYAMD_GEN_FUSION", fusion)
+        with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+            lnl, cg = e.gradient()
+            assert abs(lnl - o["lnl"]) <= 1e-10 * abs(o["lnl"])
+            np.testing.assert_allclose(cg, o["cat_grad"], rtol=1e-9, atol=1e-9 * np.abs(o["cat_grad"]).max())
+            np.testing.assert_allclose(e.pattern_log_likelihoods(), o["pattern_lk"], rtol=1e-10, atol=1e-10)
+            results[fusion] = (lnl, cg.copy())
+            ref_bg = po.branch_gradient_from_cat(o["cat_grad"], pb.cat_rates, pb.cat_props)
+            c0 = cherries[0]
+            sib = pb.right[parent[c0]] if pb.left[parent[c0]] == c0 else pb.left[parent[c0]]
+            for n in (c0, pb.left[c0], pb.right[c0], sib):
+                lt, d1, _ = e.branch_log_likelihood(n, pb.branch_lengths[n])
+                assert abs(lt - o["lnl"]) <= 1e-10 * abs(o["lnl"]), (fusion, n)
+                assert abs(d1 - ref_bg[n]) <= 1e-9 * max(1.0, np.abs(ref_bg).max()), (fusion, n)
+            # one changed tip branch under a cherry
+            t = pb.left[cherries[1]]
+            bl = pb.branch_lengths.copy()
+            bl[t] *= 1.7
+            e.set_branch_length(t, bl[t])
+            saved = pb.branch_lengths.copy()
+            pb.branch_lengths[:] = bl
+            o2 = pb.gradient()
+            pb.branch_lengths[:] = saved
+            lnl2, cg2 = e.gradient()
+            assert abs(lnl2 - o2["lnl"]) <= 1e-10 * abs(o2["lnl"])
+            np.testing.assert_allclose(cg2, o2["cat_grad"], rtol=1e-9, atol=1e-9 * np.abs(o2["cat_grad"]).max())
+    assert abs(results["1"][0] - results["0"][0]) <= 1e-12 * abs(results["0"][0])
+    np.testing.assert_allclose(results["1"][1], results["0"][1], rtol=1e-11, atol=1e-11 * np.abs(results["0"][1]).max())
+
+
 @pytest.mark.parametrize("case", ["gtr_g4_t16", "gtr_g4_t24_gaps_tipstates", "wag_g4_t12", "mg94_t8"])
 @pytest.mark.parametrize("resident", [False, True])
 def test_single_branch_evaluation_matches_reference_fixture(case, resident):
