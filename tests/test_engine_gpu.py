@@ -824,6 +824,25 @@ def test_single_branch_evaluation_without_resident_uppers(S, T, P, C, rescale):
         assert e.profile()["lower_launches"] == 0
 
 
+@pytest.mark.parametrize("S", [4, 20, 61])
+def test_tiny_trees_and_ragged_pattern_counts(S):
+    """Two to nine taxa, 1 / 2 / 15 / 16 / 17 / 65 patterns (below, at and just past a wave's 16-pattern MFMA tile and 64-lane
+    wave), one and four categories, plain and rescaled: lnL, gradient and a tip's single-branch evaluation against the oracle."""
+    for T in (2, 3, 4, 5, 9):
+        for P in (1, 2, 15, 16, 17, 65):
+            for C in (1, 4):
+                for resc in (0, 1):
+                    pb = random_problem(T, P, C, seed=7 * T + P + S, S=S, gaps=0.1, rescale=resc)
+                    o = pb.gradient()
+                    with engine_from_problem(pb, rescale=RESCALE_ALWAYS if resc else RESCALE_NEVER) as e:
+                        lnl, cg = e.gradient()
+                        assert abs(lnl - o["lnl"]) <= 1e-10 * abs(o["lnl"]), (T, P, C, resc)
+                        np.testing.assert_allclose(cg, o["cat_grad"], rtol=1e-8, atol=1e-9 * max(1e-300, np.abs(o["cat_grad"]).max()))
+                        if T > 2:
+                            lt, _, _ = e.branch_log_likelihood(0, pb.branch_lengths[0])
+                            assert abs(lt - o["lnl"]) <= 1e-10 * abs(o["lnl"]), (T, P, C, resc)
+
+
 def test_fused_cherries_at_20_states(monkeypatch):
     """20 states: cherries are fused into their parents' ops (never stored; their uppers stay in registers).  The fused schedule
     and the one that stores every node (PHYAMD_GEN_FUSION=0) must both equal the CPU oracle -- lnL, per-pattern lnL, gradient --
