@@ -113,6 +113,7 @@ struct NodeOp {
 #include "phyamd_device.inc"
 #include "phyamd_level4.inc"
 #include "phyamd_walk4.inc"
+#include "phyamd_walk4mx.inc"
 #include "phyamd_general.inc"
 #include "phyamd_patterns.inc"
 
