@@ -7,9 +7,12 @@ FETCH_SIZE reports exactly half of the bytes of a 16-B-per-lane coalesced stream
 is exact for 16-B-per-lane stores.  Only the launches of the LAST evaluation in the trace are used.
 
 usage: pmc_traffic.py TAG FETCH.csv WRITE.csv taxa patterns categories launches_per_eval out.json [BUSY.csv]
+launches_per_eval counts the pre-order kernel's launches (the chunked walk: 2); the post-order kernel's come from the
+environment variable PMC_LOWER_LAUNCHES (default: the same number).
 """
 import csv
 import json
+import os
 import sys
 
 
@@ -23,10 +26,11 @@ def main():
     tag, fetch, write = sys.argv[1], sys.argv[2], sys.argv[3]
     T, P, C, L, out = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), sys.argv[8]
     busy = sys.argv[9] if len(sys.argv) > 9 else None
-    res = {"tag": tag, "taxa": T, "patterns": P, "categories": C, "states": 4, "launches_per_eval": L, "lower_launches_per_eval": L, "source": [fetch, write] + ([busy] if busy else []),
+    LL = int(os.environ.get("PMC_LOWER_LAUNCHES", L))
+    res = {"tag": tag, "taxa": T, "patterns": P, "categories": C, "states": 4, "launches_per_eval": L, "lower_launches_per_eval": LL, "source": [fetch, write] + ([busy] if busy else []),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction); "
                      "VALU = SQ_INSTS_VALU (wave-instructions) of the same launches in a third pass"}
-    for name, key in (("upper", "k_upper4"), ("lower", "k_lower4")):
+    for name, key, L in (("upper", "k_upper4", L), ("lower", "k_lower4", LL)):
         f, n1 = per_kernel(fetch, key, L)
         w, n2 = per_kernel(write, key, L)
         assert n1 == n2 == L, (n1, n2, L)
