@@ -455,7 +455,7 @@ def main():
                                           {"GB/s": three_pass, "ratio_to_hbm_peak": three_pass / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": upper_b / launches},
                          "launches_per_eval": launches,
                          "avg_launch_ms": prof["upper_ms"] / launches,
-                         "lower_kernel": {"kernel": f"k_lower{kern}" if p["lower_launches"] == 1 or S != 4 else "k_lower4",
+                         "lower_kernel": {"kernel": f"k_lower{kern}" if p["lower_launches"] <= 2 or S != 4 else "k_lower4",
                                           "launches_per_eval": p["lower_launches"], "ms_per_eval": prof["lower_ms"]},
                          "ms_per_eval": {k: prof[k] for k in prof}},
         }

@@ -39,7 +39,7 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM
 	echo "$name done" >&2
 done
 cd "$ROOT"
-PMC_LOWER_LAUNCHES=1 python3 profiles/pmc_traffic.py "$TAG" "$OUT/${TAG}_pmc_FETCH_SIZE.csv" "$OUT/${TAG}_pmc_WRITE_SIZE.csv" 1000 1000000 4 2 "$OUT/${TAG}_traffic.json" "$OUT/${TAG}_pmc_SQ_INSTS_VALU.csv" > /dev/null
+PMC_LOWER_LAUNCHES=2 python3 profiles/pmc_traffic.py "$TAG" "$OUT/${TAG}_pmc_FETCH_SIZE.csv" "$OUT/${TAG}_pmc_WRITE_SIZE.csv" 1000 1000000 4 2 "$OUT/${TAG}_traffic.json" "$OUT/${TAG}_pmc_SQ_INSTS_VALU.csv" > /dev/null
 cp "$OUT/${TAG}_traffic.json" profiles/traffic_latest.json   # (on the box: so that the bench line below carries the measured roofline)
 unset PHYAMD_BENCH_BLOCK
 python3 bench.py --steps 5 --warmup 2 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
