@@ -857,6 +857,48 @@ def test_matrix_core_walk_matches_oracle(monkeypatch, T, P, C, fold):
         np.testing.assert_allclose(cg, o["cat_grad"], rtol=1e-9, atol=1e-9 * np.abs(o["cat_grad"]).max())
 
 
+def _caterpillar(T):
+    N = 2 * T - 1
+    left, right = np.full(N, -1, np.int32), np.full(N, -1, np.int32)
+    left[T], right[T] = 0, 1
+    for i in range(1, T - 1):
+        left[T + i], right[T + i] = T + i - 1, i + 1
+    return left, right, N - 1
+
+
+def _balanced(T):
+    N = 2 * T - 1
+    left, right = np.full(N, -1, np.int32), np.full(N, -1, np.int32)
+    level, nxt = list(range(T)), T
+    while len(level) > 1:
+        new = []
+        for a in range(0, len(level) - 1, 2):
+            left[nxt], right[nxt] = level[a], level[a + 1]
+            new.append(nxt)
+            nxt += 1
+        if len(level) % 2:
+            new.append(level[-1])
+        level = new
+    return left, right, N - 1
+
+
+@pytest.mark.parametrize("shape", [_caterpillar, _balanced])
+@pytest.mark.parametrize("T,rescale", [(8, 0), (65, 1), (256, 0), (300, 1)])
+def test_extreme_tree_shapes(shape, T, rescale):
+    """A ladder (every op has one stored child: the chunked walks find nothing to cut, nothing is ever parked) and a balanced tree
+    (cuts at every level, deepest park nesting), plain and rescaled, against the oracle."""
+    pb = random_problem(T, 130, 4, seed=T + 3, S=4, gaps=0.05, bl=(0.3, 0.9) if rescale else (0.01, 0.1), rescale=rescale)
+    left, right, root = shape(T)
+    pb.left[:] = left
+    pb.right[:] = right
+    pb.root = root
+    o = pb.gradient()
+    with engine_from_problem(pb, rescale=RESCALE_ALWAYS if rescale else RESCALE_NEVER) as e:
+        lnl, cg = e.gradient()
+        assert abs(lnl - o["lnl"]) <= 1e-10 * abs(o["lnl"])
+        np.testing.assert_allclose(cg, o["cat_grad"], rtol=1e-8, atol=1e-9 * np.abs(o["cat_grad"]).max())
+
+
 def test_fused_cherries_at_20_states(monkeypatch):
     """20 states: cherries are fused into their parents' ops (never stored; their uppers stay in registers).  The fused schedule
     and the one that stores every node (PHYAMD_GEN_FUSION=0) must both equal the CPU oracle -- lnL, per-pattern lnL, gradient --
