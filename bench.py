@@ -394,8 +394,8 @@ def main():
         value = args.steps / elapsed
         lower_b, upper_b = algorithmic_bytes(T, Pl, C, S)  # this rank's shard
         launches = max(1, p["upper_launches"])
-        # 4 states: the tree-walk kernels (the post-order walk is ONE launch, the pre-order walk one for the top of the tree and one
-        # for its cut subtrees); otherwise one launch per tree level
+        # 4 states: the tree-walk kernels (each pass is two launches: cut subtrees and the top of the tree); otherwise one launch
+        # per tree level
         kern = ("4_walk" if launches <= 2 and T > 4 else "4") if S == 4 else "_gen"
         upper_s = prof["upper_ms"] * 1e-3
         three_pass = upper_b / upper_s / 1e9 if upper_s > 0 else None
