@@ -1,7 +1,7 @@
 // phyamd_engine.hip -- MI355X (gfx950) tree-likelihood engine behind include/physher_amd.h.
 //
 // One translation unit, assembled from:
-//   phyamd_device.inc / _level4 / _walk4 / _general / _patterns   device code (kernels)
+//   phyamd_device.inc / _level4 / _walk4 / _walk4s / _general / _patterns   device code (kernels)
 //   phyamd_shard.inc        state of one engine on one GPU (= one shard of the site patterns)
 //   phyamd_schedule.inc     level and tree-walk schedules, device storage
 //   phyamd_launch.inc       kernel launches per pass
@@ -114,6 +114,7 @@ struct NodeOp {
 #include "phyamd_level4.inc"
 #include "phyamd_walk4.inc"
 #include "phyamd_walk4mx.inc"
+#include "phyamd_walk4s.inc"
 #include "phyamd_general.inc"
 #include "phyamd_patterns.inc"
 
