@@ -140,7 +140,7 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
                         multi = dict(cores=K, patterns_per_second=sum(compressed / t for t in ts), slowest_t_eval=max(ts), iters=it2)
                 except Exception as exc:
                     print(f"[bench] concurrent CPU timing skipped ({exc})", file=sys.stderr)
-                return dict(kind="reference", cores=1, t_eval=t_eval, patterns=compressed, iters=iters, lnl_ms=r["lnl_ms_per_eval"], multi=multi,
+                return dict(kind="reference", cores=1, t_eval=t_eval, patterns=compressed, iters=iters, lnl_ms=r["lnl_ms_per_eval"], multi=multi, lnl=r.get("lnl"),
                             sample=f"physher SSE path (oracle/_ref/ref_driver bench), {T} taxa x {compressed} patterns "
                                    f"(first {sp} sites of the workload: a cache-resident sample, which flatters the CPU), {iters} gradient evals after 1 warm-up, "
                                    f"scaled linearly to the full pattern count")
@@ -242,6 +242,49 @@ def time_other_config(config, device, stream, seed, evals):
     return out
 
 
+def drop_in_measure(config, device, seed, iters):
+    """What a user of the REFERENCE gets from the binding (INTEGRATION.md seam A): physher's own object graph, built by its own JSON
+    parser from a FASTA file and a Newick string, with integration/physher_device.c in front of libphyc -- timed by the protocol of
+    examples/benchmarking.c:498-503 (oracle/_ref/ref_driver bench: invalidate every node and the eigen system, then
+    TreeLikelihood_gradient with the TREE_MODEL flag), in a process of its own.  Test infrastructure built where the reference
+    tree exists (oracle/_ref travels to the GPU box prebuilt); None where it is absent."""
+    from physher_amd import synth
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    driver, shim = os.path.join(refdir, "ref_driver"), os.path.join(refdir, "libphysher_device.so")
+    if not (os.path.exists(driver) and os.path.exists(shim)):
+        return None
+    wl = WORKLOADS[config]
+    T, P, C, S = wl["taxa"], wl["patterns"], wl["categories"], wl["states"]
+    if S != 4:
+        return None
+    tree = synth.random_tree(T, np.random.default_rng(seed))
+    states = np.ascontiguousarray(evolve_on_device(tree, P, seed * 100003, device, S).cpu().numpy())
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "aln.fa"), "w") as f:
+            f.write(synth.to_fasta(tree.names, states, "nucleotide"))
+        with open(os.path.join(d, "tree.nwk"), "w") as f:
+            f.write(tree.newick() + "\n")
+        with open(os.path.join(d, "spec.txt"), "w") as f:
+            f.write(f"fasta {d}/aln.fa\nnewick {d}/tree.nwk\ndatatype nucleotide\nmodel gtr\n"
+                    f"rates {','.join(map(str, GTR_RATES[:5]))}\nfreqs {','.join(map(str, GTR_FREQS))}\n"
+                    f"categories {C}\nalpha {ALPHA}\ntipstates 1\nsse 1\n")
+        env = dict(os.environ)
+        env["LD_PRELOAD"] = shim
+        env["PHYSHER_DEVICE"] = "1"
+        env["PHYSHER_DEVICE_VERBOSE"] = "1"
+        t0 = time.perf_counter()
+        out = subprocess.run([driver, "bench", os.path.join(d, "spec.txt"), str(iters), "2"], capture_output=True, text=True, env=env, timeout=900)
+        wall = time.perf_counter() - t0
+    if out.returncode != 0:
+        return {"error": (out.stderr or out.stdout)[-400:]}
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    return {"workload": f"{wl['name']}, {T} taxa x {P} sites -> {r['patterns']} patterns x {S} states x {C} categories (BASELINE configs[{int(config[3]) - 1}]), "
+                        f"physher's own JSON model + SingleTreeLikelihood + TreeLikelihood_gradient (TREE_MODEL) with the device binding preloaded",
+            "evals_per_s": 1e3 / r["grad_ms_per_eval"], "ms_per_eval": r["grad_ms_per_eval"], "lnl_only_ms_per_eval": r["lnl_ms_per_eval"], "lnL": r["lnl"],
+            "patterns": r["patterns"], "iters": iters, "process_wall_s": wall,
+            "device_work": (out.stderr.strip().splitlines() or [""])[-1][-160:]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +300,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg2..cfg4 and lnL-only secondary measurements (N = 1 only)")
     ap.add_argument("--no-distinct-check", action="store_true", help="skip counting the distinct columns of the synthetic alignment")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the drop_in measurement (the reference's object graph through the binding)")
+    ap.add_argument("--drop-in-config", choices=("cfg2", "cfg5"), default="cfg2", help="workload of the drop_in measurement (cfg5: a 1 GB FASTA file, minutes)")
     ap.add_argument("--rescale", choices=("auto", "always", "never"), default="auto",
                     help="rescaling policy (auto = the reference's lazy switch; always: NOT the headline configuration, measures the rescaled kernels)")
     ap.add_argument("--max-device-gb", type=float, default=0.0,
@@ -477,6 +522,22 @@ def main():
             scaled = cb["t_eval"] * (P / cb["patterns"])
             out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "evals/s", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
                                    "sample_seconds_per_eval": cb["t_eval"], "sample_patterns": cb["patterns"]}
+            if cb.get("lnl") is not None:
+                # the same sample (the first sites of the workload, every site with weight 1) through the engine: the reference's lnL of
+                # the driver's own run is the yardstick (relative difference; the parity tests hold 1e-10)
+                sp = min(args.cpu_sample_patterns, states.shape[1])
+                with Engine(T, sp, S, C, device=local_rank, rescale=RESCALE_AUTO, stream=stream.cuda_stream) as chk:
+                    chk.set_topology(tree.left, tree.right, tree.root)
+                    chk.set_branch_lengths(tree.length)
+                    chk.set_eigen(ev, U, Ui)
+                    chk.set_frequencies(freqs)
+                    chk.set_category_rates(cat_rates, cat_props)
+                    chk.set_pattern_weights(np.ones(sp))
+                    for t in range(T):
+                        chk.set_tip_states(t, np.ascontiguousarray(states[t, :sp]))
+                    lnl_gpu = chk.log_likelihood()
+                rel = abs(lnl_gpu - cb["lnl"]) / abs(cb["lnl"])
+                out["cpu_baseline"]["lnl_check"] = {"lnL_reference": cb["lnl"], "lnL_engine": lnl_gpu, "relative_difference": rel, "within_1e-10": bool(rel <= 1e-10)}
             if cb.get("multi"):  # every host core busy with its own pattern shard (the reference's only way to use them)
                 m = cb["multi"]
                 out["cpu_baseline"]["all_cores"] = {"value": m["patterns_per_second"] / P, "unit": "evals/s", "cores": m["cores"],
@@ -502,6 +563,21 @@ def main():
                     out["other_configs"].append(time_other_config(cfg, device, stream, args.seed, 10))
                 except Exception as exc:  # a secondary measurement must not lose the headline line
                     out["other_configs"].append({"workload": cfg, "error": str(exc)})
+        if world == 1 and not args.no_drop_in and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1 and not args.subst_gradient:
+            try:
+                di = drop_in_measure(args.drop_in_config, device, args.seed, 20 if args.drop_in_config == "cfg2" else 5)
+            except Exception as exc:
+                di = {"error": str(exc)}
+            if di is not None:
+                if "evals_per_s" in di:  # against the raw engine on the same workload (same tree, same sites)
+                    if args.drop_in_config == "cfg5":
+                        raw = value
+                    else:
+                        same = [o for o in out.get("other_configs", []) if "configs[1]" in o.get("workload", "") and "evals_per_s" in o]
+                        raw = same[0]["evals_per_s"] if same else None
+                    di["engine_evals_per_s"] = raw
+                    di["ratio_to_engine"] = None if not raw else di["evals_per_s"] / raw
+                out["drop_in"] = di
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -3,9 +3,9 @@
  * MI355X engine (include/physher_amd.h), with the reference's object graph, JSON surface, gradient epilogue and
  * wrapper classes left exactly as they are.
  *
- * TEST INFRASTRUCTURE (reference side of the boundary).  Built only where /root/reference exists, by oracle/Makefile,
- * against the reference's headers where they lie (-I$REF/src) into oracle/_ref/libphysher_device.so; nothing of the
- * reference is copied, nothing under physher_amd/ links this file.
+ * REFERENCE SIDE OF THE BOUNDARY.  Built against physher's headers where they lie: `make -C integration PHYSHER_SRC=...` for a
+ * maintainer, oracle/Makefile into oracle/_ref/libphysher_device.so for this repository's tests; nothing of the reference is
+ * copied, nothing under physher_amd/ links this file.
  *
  * How it binds without editing the reference:
  *   - `tlk->calculate` is a function pointer (treelikelihood.h:92, set at treelikelihood.c:1064, used at :165, :327):
@@ -83,6 +83,7 @@ typedef struct binding {
 	unsigned long generation, pgrad_generation;
 	double *pgrad, *rootf;
 	size_t np;
+	bool dq_sent; /* the engine holds dQ/dtheta of the current substitution parameters (they move only with the eigen system) */
 	double *scratch; /* S*S */
 	/* CPU entry points this binding replaced */
 	double (*cpu_calculate)(SingleTreeLikelihood *);
@@ -179,6 +180,20 @@ static void explicit_matrices(binding *b, bool all, const bool *changed) {
 	if (all) die_on(phyamd_set_matrices(b->dev, b->mats), "phyamd_set_matrices");
 }
 
+/* one branch's length to the engine; closed-form models also send that node's own m->p_t matrices -- every node carries explicit
+ * matrices then, which the engine never rebuilds from the eigen system, so a length alone would leave P(old t) in place */
+static void send_branch_length(binding *b, int node, double length) {
+	SingleTreeLikelihood *tlk = b->tlk;
+	b->bl[node] = length;
+	die_on(phyamd_set_branch_length(b->dev, node, length), "phyamd_set_branch_length");
+	if (b->closed_form && !Node_isroot(Tree_node(tlk->tree, node))) {
+		const int S = b->S, C = b->C;
+		const size_t msz = (size_t)C * S * S;
+		for (int c = 0; c < C; c++) tlk->m->p_t(tlk->m, length * b->rates[c], b->mats + node * msz + (size_t)c * S * S);
+		die_on(phyamd_set_node_matrices(b->dev, node, b->mats + node * msz), "phyamd_set_node_matrices");
+	}
+}
+
 /* Site model, substitution model, frequencies, branch lengths: what _calculate_partials and p_t pull lazily per node on the
  * CPU (treelikelihood.c:1645-1696, substmodel.c:520-523) is pushed once per evaluation, and only what changed. */
 static void push_model(binding *b, bool all_nodes) {
@@ -220,6 +235,7 @@ static void push_model(binding *b, bool all_nodes) {
 				die_on(phyamd_set_rate_matrix(b->dev, b->scratch), "phyamd_set_rate_matrix");
 			}
 			model_changed = true;
+			b->dq_sent = false;
 		}
 		free(flat);
 	}
@@ -295,8 +311,7 @@ static double _calculate_device(SingleTreeLikelihood *tlk) {
 		if (idx >= 0 && !Node_isroot(Tree_node(tlk->tree, idx))) {
 			if (b->upper_node >= 0 && b->upper_node != idx) {
 				Node *prev = Tree_node(tlk->tree, b->upper_node);
-				b->bl[b->upper_node] = branch_length_of(tlk, prev);
-				die_on(phyamd_set_branch_length(b->dev, b->upper_node, b->bl[b->upper_node]), "phyamd_set_branch_length");
+				send_branch_length(b, b->upper_node, branch_length_of(tlk, prev));
 				tlk->update_nodes[b->upper_node] = false; /* :1601 */
 			}
 			Node *node = Tree_node(tlk->tree, idx);
@@ -375,16 +390,19 @@ static void device_parameter_gradient(binding *b, double *cat_gradient) {
 		b->pgrad = realloc(b->pgrad, sizeof(double) * np);
 		b->np = np;
 	}
-	double *dQ = malloc(sizeof(double) * np * S * S);
-	for (size_t p = 0; p < np; p++) {
-		/* m->dQ after the first half of m->dPdp (_gtr_dQdp, _hky_dQdp, _general_dQdp) is d(normalised Q)/d(parameter p) */
+	if (!b->dq_sent) { /* np calls of m->dPdp: once per parameter change, not once per gradient */
+		double *dQ = malloc(sizeof(double) * np * S * S);
+		for (size_t p = 0; p < np; p++) {
+			/* m->dQ after the first half of m->dPdp (_gtr_dQdp, _hky_dQdp, _general_dQdp) is d(normalised Q)/d(parameter p) */
+			m->dQ_need_update = true;
+			m->dPdp(m, (int)p, b->scratch, 0.1);
+			memcpy(dQ + p * S * S, m->dQ, sizeof(double) * S * S);
+		}
 		m->dQ_need_update = true;
-		m->dPdp(m, (int)p, b->scratch, 0.1);
-		memcpy(dQ + p * S * S, m->dQ, sizeof(double) * S * S);
+		die_on(phyamd_set_rate_matrix_derivatives(b->dev, (int)np, dQ), "phyamd_set_rate_matrix_derivatives");
+		free(dQ);
+		b->dq_sent = true;
 	}
-	m->dQ_need_update = true;
-	die_on(phyamd_set_rate_matrix_derivatives(b->dev, (int)np, dQ), "phyamd_set_rate_matrix_derivatives");
-	free(dQ);
 	double lnl;
 	const int flags = b->exact ? 0 : PHYAMD_GRAD_COMPAT_SCALED; /* the reference clears include_root_freqs here (:291-305) */
 	die_on(phyamd_parameter_gradient(b->dev, flags, &lnl, cat_gradient, b->pgrad), "phyamd_parameter_gradient");
@@ -404,6 +422,41 @@ static void device_parameter_gradient(binding *b, double *cat_gradient) {
 		free(dphi);
 	}
 	b->pgrad_generation = b->generation;
+}
+
+/* TreeLikelihood_calculate_gradient opens with pattern_likelihoods[k] = exp(pattern_lk[k]) over all patterns
+ * (treelikelihood.c:3207-3210) for the CPU kernels it then calls; the device twins below never read that array (w_k / L_k stays
+ * on the device), and at 1e5 patterns the loop costs as much as the device's whole gradient.  The loop's bound is
+ * tlk->sp->count, read per iteration: it is 0 for the duration of the call.  A maintainer writes `if (!tlk->device)` around
+ * the loop instead.  (Nothing else the function reaches on a device-enabled object reads the pattern count.) */
+void TreeLikelihood_calculate_gradient(Model *model, double *grads) {
+	static void (*real)(Model *, double *);
+	if (!real) real = next_symbol("TreeLikelihood_calculate_gradient");
+	SingleTreeLikelihood *tlk = (SingleTreeLikelihood *)model->obj;
+	if (!find_binding(tlk)) {
+		real(model, grads);
+		return;
+	}
+	const size_t count = tlk->sp->count;
+	tlk->sp->count = 0;
+	real(model, grads);
+	tlk->sp->count = count;
+}
+
+/* SingleTreeLikelihood_update_uppers (treelikelihood.c:1530-1538: what serial_brent_optimize_tree calls first, optimizer.c:125)
+ * runs the static CPU pass _calculate_simple and the CPU pre-order pass; on a device object it means "evaluate, then serve
+ * single-branch trials": the engine rebuilds the one upper a trial needs on demand */
+void SingleTreeLikelihood_update_uppers(SingleTreeLikelihood *tlk) {
+	static void (*real)(SingleTreeLikelihood *);
+	if (!find_binding(tlk)) {
+		if (!real) real = next_symbol("SingleTreeLikelihood_update_uppers");
+		real(tlk);
+		return;
+	}
+	tlk->use_upper = false;
+	tlk->calculate(tlk);
+	tlk->update_upper = false;
+	tlk->use_upper = true;
 }
 
 void update_upper_partials(SingleTreeLikelihood *tlk, Node *node, bool include_root_freqs) {
@@ -539,6 +592,7 @@ static void _handle_restore_device(Model *self, Model *model, int index) {
 	memcpy(b->props, b->st_props, sizeof(double) * b->C);
 	memcpy(b->freqs, b->st_freqs, sizeof(double) * S);
 	memcpy(b->eigen, b->st_eigen, sizeof(double) * (S + 2 * S * S));
+	b->dq_sent = false;
 	b->restore_pending = true; /* cleared by the next store or evaluation; further sub-model restores of this cycle change nothing */
 	b->generation++;
 }

@@ -16,6 +16,7 @@
  *   ref_driver dump  <spec-file> <out.json>
  *   ref_driver json  <reference-json-file> <out.json>      (run in the dir holding its data files)
  *   ref_driver bench <spec-file> <iters> <warmup>
+ *   ref_driver brent <spec-file> <out.json>     the optimiser's single-branch call pattern (optimizer.c:112-153)
  *   ref_driver attr  <attr-spec-file> <out.json>           (one discrete trait per taxon, any state count)
  *   ref_driver branch <spec-file> <out.json>               (lnL, d lnL/dt, d2 lnL/dt2 of single branches at trial lengths)
  *
@@ -361,7 +362,7 @@ static built_t build_from_attr_spec(const char *path) {
 
 static void jnum(FILE *o, double v);
 
-/* With tests/integration/physher_device.c in front of libphyc (LD_PRELOAD) the model may be evaluated on the GPU: the CPU-side
+/* With integration/physher_device.c in front of libphyc (LD_PRELOAD) the model may be evaluated on the GPU: the CPU-side
  * partial arrays are then never filled and are not dumped. */
 static int on_device(SingleTreeLikelihood *tlk) {
 	int (*f)(const SingleTreeLikelihood *) = (int (*)(const SingleTreeLikelihood *))dlsym(RTLD_DEFAULT, "SingleTreeLikelihood_on_device");
@@ -581,6 +582,55 @@ int main(int argc, char **argv) {
 			Node_set_distance(node, base);
 		}
 		fprintf(o, "],\"rescaled\":%s,\"source\":\"physher reference via oracle/ref_driver.c branch mode\"}\n", tlk->scale ? "true" : "false");
+		fclose(o);
+		return 0;
+	}
+	if (!strcmp(argv[1], "brent")) {
+		/* The call pattern of serial_brent_optimize_tree (optimizer.c:112-153) without the line search itself: use_upper on, the
+		 * branches in post-order, three trial lengths per branch through Node_set_distance + logP (single-branch evaluations
+		 * from the partials that meet on the branch, _calculate :1558-1606), the last trial kept; then use_upper off, one plain
+		 * logP and the TREE_MODEL gradient -- which must see every accepted length. */
+		spec_t sp;
+		read_spec(argv[2], &sp);
+		built_t b = build_from_spec(&sp);
+		SingleTreeLikelihood *tlk = b.mlike->obj;
+		Tree *tree = tlk->tree;
+		const int N = Tree_node_count(tree);
+		Node **nodes = Tree_get_nodes(tree, POSTORDER);
+		const double factor[3] = {0.7, 1.6, 1.15};
+		FILE *o = fopen(argv[3], "w");
+		fprintf(o, "{\"lnl_start\":%.17g,\n\"trials\":[", b.mlike->logP(b.mlike));
+		tlk->node_upper = NULL;
+		tlk->use_upper = true;
+		tlk->update_upper = true;
+		if (Node_distance(Tree_root(tree)->right) != 0) {
+			double tot = Node_distance(Tree_root(tree)->right) + Node_distance(Tree_root(tree)->left);
+			Node_set_distance(Tree_root(tree)->right, 0);
+			Node_set_distance(Tree_root(tree)->left, tot);
+		}
+		SingleTreeLikelihood_update_uppers(tlk);
+		int first = 1;
+		for (int i = 0; i < N; i++) {
+			Node *node = nodes[i];
+			if (Node_isroot(node) || (Node_isroot(Node_parent(node)) && Node_right(Node_parent(node)) == node)) continue;
+			if (tlk->node_upper == NULL) tlk->node_upper = node;
+			const double base = Node_distance(node);
+			double l0 = b.mlike->logP(b.mlike); /* Brent's first point: the current value, nothing changed */
+			fprintf(o, "%s{\"node\":%d,\"length\":%.17g,\"lnl\":%.17g}", first ? "" : ",", Node_id(node), base, l0);
+			first = 0;
+			for (int f = 0; f < 3; f++) {
+				Node_set_distance(node, base * factor[f]);
+				fprintf(o, ",{\"node\":%d,\"length\":%.17g,\"lnl\":%.17g}", Node_id(node), base * factor[f], b.mlike->logP(b.mlike));
+			}
+		}
+		tlk->use_upper = false;
+		fprintf(o, "],\n\"lnl_end\":%.17g,\n", b.mlike->logP(b.mlike));
+		SingleTreeLikelihood_update_all_nodes(tlk);
+		fprintf(o, "\"lnl_end_recomputed\":%.17g,\n", b.mlike->logP(b.mlike));
+		size_t len = TreeLikelihood_initialize_gradient(b.mlike, TREELIKELIHOOD_FLAG_TREE_MODEL);
+		double *g = TreeLikelihood_gradient(b.mlike);
+		jarr(o, "gradient_tree_end", g, len, true);
+		fprintf(o, "\"source\":\"physher reference via oracle/ref_driver.c brent mode\"}\n");
 		fclose(o);
 		return 0;
 	}

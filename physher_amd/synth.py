@@ -129,6 +129,9 @@ def distinct_patterns(tree: SynthTree, pattern_count: int, state_count: int,
 def to_fasta(names, states: np.ndarray, datatype: str = "nucleotide", gap_fraction: float = 0.0,
              rng: np.random.Generator | None = None) -> str:
     lines = []
+    if datatype in ("nucleotide", "aa") and gap_fraction == 0.0:  # one symbol per state, no gaps: a table lookup per row
+        table = np.frombuffer((NUC if datatype == "nucleotide" else AA).encode() if isinstance(NUC, str) else "".join(NUC if datatype == "nucleotide" else AA).encode(), dtype="S1")
+        return "".join(f">{name}\n{table[np.asarray(row)].tobytes().decode()}\n" for name, row in zip(names, states))
     for name, row in zip(names, states):
         if datatype == "nucleotide":
             sym = [NUC[s] for s in row]

@@ -297,9 +297,30 @@ def run_branch_trials(name):
     print(name, "branch trials:", len(data["trials"]))
 
 
+# the optimiser's call pattern (serial_brent_optimize_tree, optimizer.c:112-153) by the reference's CPU path: single-branch trial
+# evaluations with use_upper on, accepted lengths, then the plain lnL and gradient -- a closed-form model (JC69: the binding hands
+# the engine the model's own P(t) per node) and the eigen route (GTR + G4)
+BRENT_CASES = ("jc69_t12", "gtr_g4_t16")
+
+
+def run_brent(name):
+    d = os.path.join(HERE, name)
+    out = os.path.join(d, "brent_trials.json")
+    subprocess.check_call([DRIVER, "brent", "spec.txt", out], cwd=d, stdout=subprocess.DEVNULL)
+    with open(out) as f:
+        data = json.load(f)
+    with open(out, "w") as f:
+        json.dump(data, f, separators=(",", ":"))
+    print(name, "brent trials:", len(data["trials"]), "lnl", data["lnl_start"], "->", data["lnl_end"])
+
+
 if __name__ == "__main__":
     build_ref()
     only = sys.argv[1:]
+    if only == ["brent"]:
+        for name in BRENT_CASES:
+            run_brent(name)
+        sys.exit(0)
     if only == ["branch_trials"]:
         for name in BRANCH_TRIAL_CASES:
             run_branch_trials(name)

@@ -899,6 +899,36 @@ def test_extreme_tree_shapes(shape, T, rescale):
         np.testing.assert_allclose(cg, o["cat_grad"], rtol=1e-8, atol=1e-9 * np.abs(o["cat_grad"]).max())
 
 
+@pytest.mark.parametrize("shape", ["random", "caterpillar", "balanced"])
+@pytest.mark.parametrize("T", [1000, 2000])
+def test_default_walks_at_headline_taxa_match_oracle(T, shape):
+    """The DEFAULT unscaled schedule at the headline tree size and twice that (the chunked post-order walk and the streamed, chunked
+    pre-order walk: six cut subtrees, dozens of HBM park slots, LDS parks, table blocks) against the CPU oracle: lnL, per-pattern
+    lnL, the full per-category gradient and the lower partial of every node the walk stores.  A pattern count that is not a
+    multiple of the wave, gaps, and branches short enough that 2000 taxa stay above the underflow that switches rescaling on."""
+    bl = (0.004, 0.04) if T == 1000 else (0.002, 0.02)
+    pb = random_problem(T, 200, 4, seed=7000 + T, shape=shape, gaps=0.03, bl=bl)  # (the sites are evolved on the tree they are evaluated on)
+    o = pb.gradient(want_partials=True)
+    assert not o["rescaled"] and np.isfinite(o["lnl"])
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        lnl, cg = e.gradient()
+        assert not e.rescaling
+        assert abs(lnl - o["lnl"]) <= 1e-10 * abs(o["lnl"])
+        np.testing.assert_allclose(e.pattern_log_likelihoods(), o["pattern_lk"], rtol=1e-11, atol=1e-11)
+        assert np.abs(cg - o["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(o["cat_grad"]).max())
+        stored = 0
+        for n in range(pb.T, pb.N):
+            try:
+                got = e.partials(n)
+            except Exception:  # fused into its parent (cherry, cherry + tip, DEEP): never stored by this schedule
+                continue
+            stored += 1
+            np.testing.assert_allclose(got, o["lower"][n], rtol=1e-9, atol=1e-300)
+        assert stored >= T // 4  # about a third of the internal nodes of a random tree; every second one of a ladder
+        p = e.profile()
+        assert p["lower_launches"] <= 2 and p["upper_launches"] <= 2  # the walks ran (a level schedule takes one launch per tree level)
+
+
 def test_fused_cherries_at_20_states(monkeypatch):
     """20 states: cherries are fused into their parents' ops (never stored; their uppers stay in registers).  The fused schedule
     and the one that stores every node (PHYAMD_GEN_FUSION=0) must both equal the CPU oracle -- lnL, per-pattern lnL, gradient --

@@ -1,4 +1,4 @@
-"""CPU-only checks of the seam-A binding (tests/integration/physher_device.c, built into oracle/_ref/ where the reference tree
+"""CPU-only checks of the seam-A binding (integration/physher_device.c, built into oracle/_ref/ where the reference tree
 exists): it exports what INTEGRATION.md says, leaves objects that were not moved to the device exactly on the reference's CPU
 path, and fails loudly -- never a silent CPU run -- when a device is asked for and there is none."""
 import json

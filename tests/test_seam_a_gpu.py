@@ -1,5 +1,5 @@
 """Seam A: the REFERENCE's own object graph -- JSON model, SingleTreeLikelihood, gradient epilogue, its
-C++ wrapper -- evaluated on the HIP engine through tests/integration/physher_device.c.
+C++ wrapper -- evaluated on the HIP engine through integration/physher_device.c.
 
 Everything executed here was built by oracle/Makefile (target `device`) from the reference's sources where they lie, into
 oracle/_ref/ (prebuilt files travel to the GPU box; /root/reference does not and is not read):
@@ -94,6 +94,29 @@ def test_reference_object_graph_on_device_matches_cpu_fixture(case, tmp_path):
     factor = (10 if codon else 1) * (1e3 if multi else 1)
     close_where_finite(dev["gradient_tree"], gold["gradient_tree"], 1e-5 if lossy else 1e-9 * factor, "gradient_tree", underflows=lossy or multi)
     close_where_finite(dev["gradient_all"], gold["gradient_all"], 1e-5 if lossy else 1e-8 * factor, "gradient_all", underflows=lossy or multi)
+
+
+@pytest.mark.parametrize("case", ["jc69_t12", "gtr_g4_t16"])
+def test_brent_call_pattern_on_device(case, tmp_path):
+    """The optimiser's fast path through the binding (serial_brent_optimize_tree's call pattern, optimizer.c:112-153; ref_driver
+    brent): use_upper on, three trial lengths per branch as single-branch device evaluations, every last trial kept, then the plain
+    lnL and the TREE_MODEL gradient.  A closed-form model (JC69: every node carries the model's own P(t), which must follow an
+    accepted length) and the eigen route, against what the reference's CPU path printed for the same calls."""
+    with open(os.path.join(GOLDEN, case, "brent_trials.json")) as f:
+        gold = json.load(f)
+    out_json = tmp_path / "brent.json"
+    out = run([DRIVER, "brent", "spec.txt", str(out_json)], os.path.join(GOLDEN, case), device_env(PHYSHER_DEVICE=1))
+    lik, grad, branch = device_work(out.stderr)
+    assert branch >= len(gold["trials"]) // 2 and grad >= 1, (lik, grad, branch)
+    with open(out_json) as f:
+        dev = json.load(f)
+    assert len(dev["trials"]) == len(gold["trials"])
+    for got, want in zip(dev["trials"], gold["trials"]):
+        assert got["node"] == want["node"] and got["length"] == want["length"]
+        assert abs(got["lnl"] - want["lnl"]) <= 1e-9 * abs(want["lnl"]), (got, want)
+    for key in ("lnl_start", "lnl_end", "lnl_end_recomputed"):
+        assert abs(dev[key] - gold[key]) <= 1e-10 * abs(gold[key]), (key, dev[key], gold[key])
+    close_where_finite(dev["gradient_tree_end"], gold["gradient_tree_end"], 1e-9, "gradient after the accepted lengths")
 
 
 @pytest.mark.parametrize("case", sorted(JSON_CASES))
