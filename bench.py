@@ -309,6 +309,12 @@ def main():
                          "processed in tiles through one set of partial arrays (per-kernel roofline figures then describe the last tile)")
     ap.add_argument("--subst-gradient", action="store_true",
                     help="NOT the headline metric: each step also yields d lnL / d(5 GTR rates, 4 frequencies) (SURVEY 8f.1) in the same two passes")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs inside ONE process (phyamd_create_sharded: one engine, stream and host thread per GPU, results added pairwise on the "
+                         "host) instead of one process per GPU + RCCL; launch WITHOUT torch.distributed.run.  PHYAMD_BENCH_DEVICE_IDS=0,0,.. rehearses "
+                         "it on fewer GPUs")
+    ap.add_argument("--deterministic-sum", action="store_true",
+                    help="N > 1 ranks: one all-gather + the pairwise sum of physher_amd/sharding.py::tree_sum instead of one all-reduce: bit for bit the one-GPU result")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run of this workload")
     args = ap.parse_args()
@@ -319,7 +325,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    single = args.single_process and args.gpus > 1
+    if single and world != 1:
+        raise SystemExit("--single-process runs every GPU from ONE process: launch it without torch.distributed.run")
+    if not single and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
@@ -338,7 +347,7 @@ def main():
 
     from physher_amd import synth
     from physher_amd.engine import RESCALE_ALWAYS, RESCALE_AUTO, RESCALE_NEVER, Engine
-    from physher_amd.sharding import ShardedLikelihood, shard_range
+    from physher_amd.sharding import ShardedLikelihood, epilogue, reduction_levels, shard_range
 
     wl = WORKLOADS[args.config]
     T = args.taxa or wl["taxa"]
@@ -367,7 +376,7 @@ def main():
     cat_rates, cat_props = category_rates(C)
     freqs, ev, U, Ui, model_name = named_model(args.config, args.seed)
     distinct_note = "distinctness not checked on this rank"
-    if world == 1 and not args.no_distinct_check:
+    if world == 1 and not single and not args.no_distinct_check:
         nd = count_distinct_patterns(states)
         distinct_note = "device pattern compressor declined: not checked" if nd is None else f"{nd} of the {P} sites are distinct columns"
 
@@ -376,8 +385,17 @@ def main():
     # stream of its own is not ordered with torch's work -- the reduction could read the result vector before it is written
     stream = torch.cuda.Stream(device)
     torch.cuda.set_stream(stream)
-    eng = Engine(T, Pl, S, C, device=local_rank, rescale={"auto": RESCALE_AUTO, "always": RESCALE_ALWAYS, "never": RESCALE_NEVER}[args.rescale],
-                 stream=stream.cuda_stream, max_device_bytes=int(args.max_device_gb * 1e9))
+    rescale_policy = {"auto": RESCALE_AUTO, "always": RESCALE_ALWAYS, "never": RESCALE_NEVER}[args.rescale]
+    if single:  # one handle = a group of shards, one per GPU (the same ordinal may repeat: a rehearsal on fewer GPUs)
+        ids = os.environ.get("PHYAMD_BENCH_DEVICE_IDS")
+        devices = [int(x) for x in ids.split(",")] if ids else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit(f"PHYAMD_BENCH_DEVICE_IDS lists {len(devices)} devices, --gpus is {args.gpus}")
+        eng = Engine(T, Pl, S, C, rescale=rescale_policy, devices=devices)
+    else:
+        eng = Engine(T, Pl, S, C, device=local_rank, rescale=rescale_policy, stream=stream.cuda_stream, max_device_bytes=int(args.max_device_gb * 1e9))
+        if world > 1:
+            eng.set_reduction_levels(reduction_levels(P, world))  # this rank's patterns are a subtree of the one-GPU summation
     eng.set_topology(tree.left, tree.right, tree.root)
     eng.set_branch_lengths(tree.length)
     eng.set_eigen(ev, U, Ui)
@@ -406,7 +424,14 @@ def main():
         else:
             eng.gradient_device(out.data_ptr())  # HIP kernels on torch's current stream; [lnL, g[node][cat]] stays on the device
 
-    step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result, via_host=rehearsal, tail=n_tail)  # + one RCCL all-reduce + host epilogue
+    if single:
+        def step():  # every shard evaluates on its own GPU at once; the 64 KB results are added pairwise on the host (phyamd_abi.inc)
+            eng.set_branch_lengths(tree.length)
+            lnl_, cg_ = eng.gradient()
+            return epilogue(np.concatenate([[lnl_], cg_.reshape(-1)]), N, cat_rates, cat_props)
+    else:
+        step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result, via_host=rehearsal, tail=n_tail,
+                                 deterministic=args.deterministic_sum)  # + one RCCL all-reduce (or all-gather) + host epilogue
 
     def fence():
         torch.cuda.synchronize(device)
@@ -472,7 +497,7 @@ def main():
                       + (" [+ 9 substitution-parameter gradients per eval: NOT the headline metric]" if args.subst_gradient else ""),
             "value": value,
             "unit": "evals/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus if single else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -485,7 +510,9 @@ def main():
                                    f"(BASELINE configs[{int(args.config[3]) - 1}] shape; {Pl} patterns on this rank); "
                                    f"patterns = sites evolved down the tree on the GPU with integer weights 1..3 standing in for multiplicities, "
                                    f"NOT de-duplicated ({distinct_note})",
-                       "taxa": T, "patterns": P, "categories": C, "states": S, "patterns_per_gpu": Pl, "lnL": lnl,
+                       "parallelism": (f"{args.gpus} GPUs in one process (phyamd_create_sharded), host sum" if single else
+                                       f"{world} process(es), one per GPU" + ("" if world == 1 else (", one all-gather + pairwise sum" if args.deterministic_sum else ", one RCCL all-reduce"))),
+                       "taxa": T, "patterns": P, "categories": C, "states": S, "patterns_per_gpu": Pl // args.gpus if single else Pl, "lnL": lnl,
                        "rescaling": eng.rescaling, "device_bytes": p["device_bytes"], "tiles": p["tiles"]},
             "roofline": {"bound": "hbm", "kernel": f"k_upper{kern} (pre-order pass + fused branch gradient)",
                          # achieved / frac: MEASURED HBM bytes of the launch (PMC, per the guide's FETCH_SIZE / WRITE_SIZE recipe)
@@ -517,7 +544,7 @@ def main():
         if p["tiles"] > 1:  # the engine's per-kernel timings describe the last tile only: no roofline claim for a tiled run
             out["roofline"] = {"bound": "hbm", "kernel": out["roofline"]["kernel"], "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                                "traffic": None, "note": f"patterns processed in {p['tiles']} tiles (--max-device-gb): per-launch figures not comparable"}
-        if world == 1 and not args.no_cpu_baseline and S == 4:
+        if world == 1 and not single and not args.no_cpu_baseline and S == 4:
             cb = cpu_baseline(tree, states, weights, cat_rates, args.cpu_sample_patterns, args.cpu_budget_s)
             scaled = cb["t_eval"] * (P / cb["patterns"])
             out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "evals/s", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
@@ -543,7 +570,7 @@ def main():
                 out["cpu_baseline"]["all_cores"] = {"value": m["patterns_per_second"] / P, "unit": "evals/s", "cores": m["cores"],
                                                     "sample": f"{m['cores']} concurrent single-thread instances of the same sample, {m['iters']} gradient evals each; "
                                                               f"aggregate pattern throughput scaled to the full pattern count"}
-        if (world == 1 and not args.no_other_configs and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1
+        if (world == 1 and not single and not args.no_other_configs and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1
                 and not args.subst_gradient):
             # SURVEY 8d secondary metric (examples/benchmarking.c:466-471): lnL only, full recompute, result on the host
             evals = max(3, args.steps)
@@ -563,7 +590,7 @@ def main():
                     out["other_configs"].append(time_other_config(cfg, device, stream, args.seed, 10))
                 except Exception as exc:  # a secondary measurement must not lose the headline line
                     out["other_configs"].append({"workload": cfg, "error": str(exc)})
-        if world == 1 and not args.no_drop_in and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1 and not args.subst_gradient:
+        if world == 1 and not single and not args.no_drop_in and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1 and not args.subst_gradient:
             try:
                 di = drop_in_measure(args.drop_in_config, device, args.seed, 20 if args.drop_in_config == "cfg2" else 5)
             except Exception as exc:

@@ -238,6 +238,13 @@ typedef struct {
 	int64_t device_bytes; /* resident device memory of this engine */
 	int32_t tiles;         /* pattern tiles per evaluation */
 } phyamd_profile;
+/* Sums over patterns (lnL, gradient rows of the default 4-state path) are formed over the engine's blocks of 64 patterns in an
+ * order fixed by the pattern range alone: the block range is bisected `levels` times (default 3: eight segments), each segment
+ * summed in block order, the segments added pairwise.  An engine that holds one half / quarter / eighth of a larger pattern list
+ * cut by the same bisection (physher_amd/sharding.py::shard_range, phyamd_create_sharded with 2 / 4 / 8 devices) runs with
+ * 2 / 1 / 0 levels; adding the shards' results pairwise then gives bit for bit the one-engine result.  Replaces nothing in the
+ * reference (its sums are sequential, treelikelihood.c:1482-1487); SURVEY 8e "deterministic alternative". */
+int phyamd_set_reduction_levels(phyamd_engine *e, int levels);
 int phyamd_set_profiling(phyamd_engine *e, int on);
 int phyamd_get_profile(phyamd_engine *e, phyamd_profile *out);
 

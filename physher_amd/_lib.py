@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PHYAMD_LIB: load another build of the same ABI (A/B experiments with kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("PHYAMD_LIB") or os.path.join(_HERE, "libphysher_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK, EINVAL, EDEVICE, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
 RESCALE_NEVER, RESCALE_ALWAYS, RESCALE_AUTO = 0, 1, 2
@@ -75,6 +75,7 @@ SYMBOLS = [
     ("phyamd_is_rescaling", C.c_int, [_P]),
     ("phyamd_set_rescaling", C.c_int, [_P, C.c_int]),
     ("phyamd_set_keep_partials", C.c_int, [_P, C.c_int]),
+    ("phyamd_set_reduction_levels", C.c_int, [_P, C.c_int]),
     ("phyamd_set_profiling", C.c_int, [_P, C.c_int]),
     ("phyamd_get_profile", C.c_int, [_P, C.POINTER(Profile)]),
     ("phyamd_store", C.c_int, [_P]),

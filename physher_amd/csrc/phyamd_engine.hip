@@ -39,7 +39,7 @@
 
 #include "physher_amd.h"
 
-#define PHYAMD_ABI_VERSION 4
+#define PHYAMD_ABI_VERSION 5
 
 namespace {
 

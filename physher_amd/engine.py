@@ -228,6 +228,11 @@ class Engine:
     def set_keep_partials(self, on=True):
         self._check(self._lib.phyamd_set_keep_partials(self._h, int(on)))
 
+    def set_reduction_levels(self, levels):
+        """3 (default): this engine sums its pattern blocks over eight bisection segments; an engine holding 1 / 2^k of a larger
+        pattern list cut by sharding.shard_range runs with 3 - k (see include/physher_amd.h)."""
+        self._check(self._lib.phyamd_set_reduction_levels(self._h, int(levels)))
+
     def set_profiling(self, on=True):
         self._check(self._lib.phyamd_set_profiling(self._h, int(on)))
 

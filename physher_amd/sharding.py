@@ -11,26 +11,74 @@ from __future__ import annotations
 import numpy as np
 
 
+WAVE = 64  # patterns per block of the engine's per-block sums
+
+
+def _bisect(lo, hi, levels, out):
+    if levels == 0:
+        out.append(lo)
+        return
+    mid = lo + (hi - lo) // 2
+    _bisect(lo, mid, levels - 1, out)
+    _bisect(mid, hi, levels - 1, out)
+
+
 def shard_range(pattern_count: int, rank: int, world: int):
-    """[lo, hi) of rank's patterns; ranges are contiguous, disjoint, cover everything, differ by at most 1 in size."""
+    """[lo, hi) of rank's patterns; ranges are contiguous, disjoint and cover everything.
+
+    world = 2, 4, 8: the range of 64-pattern blocks is bisected 1, 2, 3 times (mid = lo + (hi - lo) // 2) -- the segments the engine
+    itself sums by (phyamd_set_reduction_levels) -- so every rank holds a subtree of the one-GPU summation and the pairwise sum
+    of the ranks' results (tree_sum) is bit for bit the one-GPU result.  Other world sizes: equal parts."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world {world}")
+    nb = (pattern_count + WAVE - 1) // WAVE
+    if world in (2, 4, 8) and nb >= world:
+        bounds = []
+        _bisect(0, nb, {2: 1, 4: 2, 8: 3}[world], bounds)
+        bounds.append(nb)
+        return bounds[rank] * WAVE, min(pattern_count, bounds[rank + 1] * WAVE)
     return rank * pattern_count // world, (rank + 1) * pattern_count // world
 
 
-def all_reduce_result(result, world: int, via_host: bool = False):
+def reduction_levels(pattern_count: int, world: int) -> int:
+    """levels for Engine.set_reduction_levels on one rank of `world` (see shard_range)."""
+    nb = (pattern_count + WAVE - 1) // WAVE
+    return 3 - {2: 1, 4: 2, 8: 3}[world] if world in (2, 4, 8) and nb >= world else 3
+
+
+def tree_sum(parts):
+    """pairwise sum of the ranks' vectors up the bisection tree (2, 4 or 8 of them), in rank order otherwise"""
+    parts = list(parts)
+    if len(parts) in (2, 4, 8):
+        while len(parts) > 1:
+            parts = [parts[i] + parts[i + 1] for i in range(0, len(parts), 2)]
+        return parts[0]
+    total = parts[0]
+    for p in parts[1:]:
+        total = total + p
+    return total
+
+
+def all_reduce_result(result, world: int, via_host: bool = False, deterministic: bool = False):
     """In-place SUM of the per-shard [lnL, cat-gradient] vector (a torch tensor on the engine's device).
 
+    Default: ONE all-reduce (RCCL over xGMI on GPUs) -- the order of the additions is the collective's.
+    deterministic: ONE all-gather of the same 64 KB vectors and the pairwise tree_sum on every rank -- with shard_range's
+    ranges the result is bit for bit that of one GPU.
     via_host: rehearsal mode for a one-GPU box (several ranks share the card, gloo group): the 64 KB vector makes a
     round trip through host memory because gloo cannot reduce device tensors on ROCm."""
     if world > 1:
+        import torch
         import torch.distributed as dist
-        if via_host and result.is_cuda:
-            tmp = result.cpu()
-            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
-            result.copy_(tmp)
+        src = result.cpu() if (via_host and result.is_cuda) else result
+        if deterministic:
+            parts = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(parts, src)
+            src = tree_sum(parts)
         else:
-            dist.all_reduce(result, op=dist.ReduceOp.SUM)
+            dist.all_reduce(src, op=dist.ReduceOp.SUM)
+        if src is not result:
+            result.copy_(src)
     return result
 
 
@@ -53,11 +101,12 @@ class ShardedLikelihood:
     kernels.  (Handle 0, torch's default stream, means "engine-owned stream" to phyamd_create and is NOT ordered with torch.)
     """
 
-    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False, tail=0):
+    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False, tail=0, deterministic=False):
         """tail > 0: the vector carries `tail` more per-shard sums after the cat-gradient (Engine.parameter_gradient_device:
         substitution-parameter sums, then the root frequency term); they ride in the same all-reduce and are returned third."""
         self.tail = tail
         self.via_host = via_host
+        self.deterministic = deterministic
         self.evaluate_shard = evaluate_shard
         self.N = node_count
         self.cat_rates = np.asarray(cat_rates, dtype=np.float64)
@@ -67,7 +116,7 @@ class ShardedLikelihood:
 
     def __call__(self):
         self.evaluate_shard(self.result)
-        all_reduce_result(self.result, self.world, self.via_host)
+        all_reduce_result(self.result, self.world, self.via_host, self.deterministic)
         host = self.result.detach().cpu().numpy()
         lnl, grad = epilogue(host, self.N, self.cat_rates, self.cat_props)
         if self.tail:

@@ -67,6 +67,27 @@ def test_sharded_engine_matches_oracle(S, T, P, C, n, rescale):
             e.gradient_device(0)
 
 
+@pytest.mark.parametrize("P", [6000, 4133, 100_003])
+def test_result_does_not_depend_on_the_shard_count(P):
+    """SURVEY 8e "deterministic alternative": lnL and the gradient of the default (unscaled, 4-state) path are sums over blocks
+    of 64 patterns in an order fixed by the pattern list alone -- eight bisection segments, added pairwise -- and 2, 4 or 8
+    shards are subtrees of that bisection whose results the host adds pairwise: every shard count returns the SAME BITS."""
+    pb = random_problem(40, P, 4, seed=9400 + P % 97, gaps=0.02)
+    results = {}
+    for n in (1, 2, 4, 8):
+        with (engine_from_problem(pb, rescale=RESCALE_NEVER, devices=device_list(n)) if n > 1 else engine_from_problem(pb, rescale=RESCALE_NEVER)) as e:
+            lnl0 = e.log_likelihood()
+            lnl, cg = e.gradient()
+            assert lnl0 == lnl
+            results[n] = (lnl, cg.copy())
+    ref = pb.gradient()
+    assert abs(results[1][0] - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+    assert np.abs(results[1][1] - ref["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+    for n in (2, 4, 8):
+        assert results[n][0] == results[1][0], (n, results[n][0], results[1][0])
+        assert np.array_equal(results[n][1], results[1][1]), n
+
+
 def test_sharded_parameter_gradient_matches_oracle():
     S, T, P, C, n = 4, 30, 700, 4, 2
     pb = random_problem(T, P, C, seed=9300, S=S, gaps=0.02)

@@ -61,6 +61,10 @@ def _worker(rank, world, port, out_dir):
     lnl2, bg2, tail = ShardedLikelihood(evaluate_shard_params, pb.N, pb.cat_rates, pb.cat_props, world, buf2, tail=7)()
     ref_tail = np.concatenate([po.parameter_gradient(pb, dQ)[1], po.root_frequency_term(pb)])
     ok = ok and lnl2 == lnl and np.array_equal(bg2, bg) and np.abs(tail - ref_tail).max() <= 1e-10 * max(1.0, np.abs(ref_tail).max())
+    # the deterministic form: one all-gather, then the pairwise sum every rank forms for itself
+    buf3 = torch.zeros(1 + pb.N * pb.C, dtype=torch.float64)
+    lnl3, bg3 = ShardedLikelihood(evaluate_shard, pb.N, pb.cat_rates, pb.cat_props, world, buf3, deterministic=True)()
+    ok = ok and abs(lnl3 - full["lnl"]) <= 1e-11 * abs(full["lnl"]) and np.abs(bg3 - ref_bg).max() <= 1e-10 * max(1.0, np.abs(ref_bg).max())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate([[float(ok), lnl, hi - lo], bg]))
     dist.barrier()
     dist.destroy_process_group()
@@ -74,7 +78,18 @@ def test_two_rank_sharded_likelihood(tmp_path):
     assert r0[0] == 1.0 and r1[0] == 1.0          # both ranks match the unsharded oracle
     assert r0[1] == r1[1]                           # and hold the identical all-reduced lnL
     assert np.array_equal(r0[3:], r1[3:])
-    assert r0[2] + r1[2] == 501 and abs(r0[2] - r1[2]) <= 1
+    assert r0[2] + r1[2] == 501 and abs(r0[2] - r1[2]) <= 64  # whole 64-pattern blocks
+
+
+def test_tree_sum_is_the_bisection_order():
+    from physher_amd.sharding import reduction_levels, tree_sum
+    rng = np.random.default_rng(3)
+    parts = [rng.normal(size=5) * 10.0 ** rng.integers(-8, 8, size=5) for _ in range(8)]
+    want = ((parts[0] + parts[1]) + (parts[2] + parts[3])) + ((parts[4] + parts[5]) + (parts[6] + parts[7]))
+    assert np.array_equal(tree_sum(parts), want)
+    assert np.array_equal(tree_sum(parts[:2]), parts[0] + parts[1])
+    assert np.array_equal(tree_sum(parts[:3]), (parts[0] + parts[1]) + parts[2])
+    assert [reduction_levels(1_000_000, w) for w in (1, 2, 4, 8, 3)] == [3, 2, 1, 0, 3]
 
 
 @pytest.mark.parametrize("P,world", [(1_000_000, 8), (1001, 4), (7, 8), (5, 2)])
@@ -84,6 +99,11 @@ def test_shard_ranges_partition_the_patterns(P, world):
     assert edges[0][0] == 0 and edges[-1][1] == P
     assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
     sizes = [b - a for a, b in edges]
-    assert max(sizes) - min(sizes) <= 1
+    assert max(sizes) - min(sizes) <= 127  # 2 / 4 / 8 ranks: whole 64-pattern blocks by bisection (the engine's summation segments)
+    if world in (2, 4, 8) and (P + 63) // 64 >= world:
+        assert all(a % 64 == 0 for a, _ in edges)
+        # every rank's range is a subtree of the bisection of the whole block range: halves of halves
+        half = shard_range(P, 0, 2)[1]
+        assert any(b == half for _, b in edges)
     with pytest.raises(ValueError):
         shard_range(P, world, world)
