@@ -472,17 +472,29 @@ def main():
         # PMC figures of the same workload (profiles/collect.sh -> profiles/traffic_latest.json): HBM bytes and vector-ALU
         # wave-instructions per launch of the dominant kernel.  They describe THIS shape only: another shape reports null.
         traffic = valu_insts = None
-        pmc_source = None
+        pmc_source = pmc_note = None
+        tj = {}
         if os.path.exists(args.traffic_json):
             try:
+                import hashlib
                 with open(args.traffic_json) as f:
                     tj = json.load(f)
-                if tj.get("states", 4) == S and tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C and tj.get("launches_per_eval") == launches:
+                with open(os.path.join(ROOT, "physher_amd", "libphysher_amd.so"), "rb") as f:
+                    lib_hash = hashlib.sha256(f.read()).hexdigest()
+                same_shape = tj.get("states", 4) == S and tj.get("taxa") == T and tj.get("patterns") == Pl and tj.get("categories") == C and tj.get("launches_per_eval") == launches
+                if not same_shape:
+                    pmc_note = "the PMC profile describes another workload shape"
+                elif tj.get("library_sha256") != lib_hash:
+                    pmc_note = f"the PMC profile ({tj.get('tag')}) was collected with another build of libphysher_amd.so: re-run profiles/collect.sh"
+                else:
                     traffic = tj["upper_bytes_per_launch"]
                     valu_insts = tj.get("upper_valu_insts_per_launch")
                     pmc_source = tj.get("tag")
-            except Exception:
+            except Exception as exc:
                 traffic = None
+                pmc_note = f"PMC profile unreadable: {exc}"
+        else:
+            pmc_note = "no PMC profile (profiles/traffic_latest.json)"
         achieved = traffic * launches / upper_s / 1e9 if traffic is not None and upper_s > 0 else None
         valu = None
         if valu_insts is not None and upper_s > 0:
@@ -519,7 +531,7 @@ def main():
                          # over the live HIP-event time of the same kernel; null when no PMC file matches this shape
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "pmc_profile": pmc_source,
+                         "traffic": traffic, "pmc_profile": pmc_source, "pmc_note": pmc_note, "kernel_resources": tj.get("kernels") if traffic is not None else None,
                          "valu": valu,
                          # the reference's three-pass algorithmic bytes over the same time: the fused kernels move about
                          # a tenth of them, so this ratio exceeds 1 and is NOT a fraction of any roof

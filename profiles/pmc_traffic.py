@@ -22,6 +22,23 @@ def per_kernel(fn, key, launches, counter=None):
     return sum(float(r["Counter_Value"]) for r in rows), len(rows)
 
 
+def library_hash():
+    """sha256 of the engine library the profiled process loaded: bench.py reports roofline.frac only for the same binary"""
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, "physher_amd", "libphysher_amd.so"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def kernel_resources(fn, key):
+    """registers and LDS of the kernel's launches as the profiler saw them"""
+    for r in csv.DictReader(open(fn)):
+        if key in r["Kernel_Name"]:
+            return {"kernel": r["Kernel_Name"].split("(")[0].split("::")[-1].strip(), "vgpr": int(r["VGPR_Count"]), "accum_vgpr": int(r["Accum_VGPR_Count"]),
+                    "sgpr": int(r["SGPR_Count"]), "lds_bytes": int(r["LDS_Block_Size"]), "workgroup": int(r["Workgroup_Size"])}
+    return None
+
+
 def main():
     tag, fetch, write = sys.argv[1], sys.argv[2], sys.argv[3]
     T, P, C, L, out = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), sys.argv[8]
@@ -30,6 +47,8 @@ def main():
     res = {"tag": tag, "taxa": T, "patterns": P, "categories": C, "states": 4, "launches_per_eval": L, "lower_launches_per_eval": LL, "source": [fetch, write] + ([busy] if busy else []),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction); "
                      "VALU = SQ_INSTS_VALU (wave-instructions) of the same launches in a third pass"}
+    res["library_sha256"] = library_hash()
+    res["kernels"] = {"upper": kernel_resources(fetch, "k_upper4"), "lower": kernel_resources(fetch, "k_lower4")}
     for name, key, L in (("upper", "k_upper4", L), ("lower", "k_lower4", LL)):
         f, n1 = per_kernel(fetch, key, L)
         w, n2 = per_kernel(write, key, L)
