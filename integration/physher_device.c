@@ -62,6 +62,7 @@ typedef struct binding {
 	Model *model;
 	phyamd_engine *dev;
 	int N, T, P, S, C;
+	int Sp; /* the engine's state count: S, or the next count it has kernels for (4, 20, 60, 61) -- the extra states are inert */
 	bool exact; /* PHYSHER_DEVICE_EXACT: exact derivatives instead of the reference's folded / per-category forms */
 	/* what the engine holds now: parameters are pushed only when they differ (update_nodes[] + need_update semantics) */
 	bool pushed;
@@ -84,7 +85,7 @@ typedef struct binding {
 	double *pgrad, *rootf;
 	size_t np;
 	bool dq_sent; /* the engine holds dQ/dtheta of the current substitution parameters (they move only with the eigen system) */
-	double *scratch; /* S*S */
+	double *scratch; /* 2 * Sp * Sp */
 	/* CPU entry points this binding replaced */
 	double (*cpu_calculate)(SingleTreeLikelihood *);
 	void (*cpu_store)(Model *);
@@ -157,13 +158,18 @@ static double branch_length_of(SingleTreeLikelihood *tlk, Node *n) {
 /* ------------------------------------------------------------------------------------------------------------ */
 /* parameters -> engine                                                                                           */
 
+/* eval[Sp] | evec[Sp][Sp] | ivec[Sp][Sp]; padding states (Sp > S: a state count without kernels of its own, as the reference's
+ * generic kernels take any, treelikelihoodX.c:43-576): eigenvalue 0 with unit eigenvectors -- P(t) is the identity on them, their
+ * frequency and every tip partial on them is 0, so nothing enters or leaves them and lnL and all gradients are the S-state model's */
 static void flatten_eigen(const binding *b, const EigenDecomposition *eg, double *out) {
-	const int S = b->S;
+	const int S = b->S, Sp = b->Sp;
+	memset(out, 0, sizeof(double) * (Sp + 2 * (size_t)Sp * Sp));
 	memcpy(out, eg->eval, sizeof(double) * S);
+	for (int i = 0; i < Sp; i++) out[Sp + i * Sp + i] = out[Sp + Sp * Sp + i * Sp + i] = 1.0;
 	for (int i = 0; i < S; i++)
 		for (int j = 0; j < S; j++) {
-			out[S + i * S + j] = eg->evec[i][j];
-			out[S + S * S + i * S + j] = eg->Invevec[i][j];
+			out[Sp + i * Sp + j] = eg->evec[i][j];
+			out[Sp + Sp * Sp + i * Sp + j] = eg->Invevec[i][j];
 		}
 }
 
@@ -225,11 +231,18 @@ static void push_model(binding *b, bool all_nodes) {
 			fprintf(stderr, "physher device backend: eigen decomposition of %s failed\n", m->name);
 			exit(2);
 		}
-		double *flat = malloc(sizeof(double) * (S + 2 * S * S));
+		for (int i = 0; i < S; i++)
+			if (eg->evali[i] != 0.0) { /* (a non-reversible Q may have complex pairs; the CPU path works in complex arithmetic then) */
+				fprintf(stderr, "physher device backend: %s has complex eigenvalues, the device engine takes real eigen systems\n", m->name);
+				exit(2);
+			}
+		const int Sp = b->Sp;
+		const size_t esz = (size_t)Sp + 2 * (size_t)Sp * Sp;
+		double *flat = malloc(sizeof(double) * esz);
 		flatten_eigen(b, eg, flat);
-		if (full || memcmp(flat, b->eigen, sizeof(double) * (S + 2 * S * S))) {
-			memcpy(b->eigen, flat, sizeof(double) * (S + 2 * S * S));
-			die_on(phyamd_set_eigen(b->dev, b->eigen, b->eigen + S, b->eigen + S + S * S), "phyamd_set_eigen");
+		if (full || memcmp(flat, b->eigen, sizeof(double) * esz)) {
+			memcpy(b->eigen, flat, sizeof(double) * esz);
+			die_on(phyamd_set_eigen(b->dev, b->eigen, b->eigen + Sp, b->eigen + Sp + Sp * Sp), "phyamd_set_eigen");
 			if (b->closed_form) { /* the gradient's (dP/dt) p = Q (P p) takes the model's Q as it stands, not U L U^-1 */
 				for (int i = 0; i < S; i++) memcpy(b->scratch + i * S, m->Q[i], sizeof(double) * S);
 				die_on(phyamd_set_rate_matrix(b->dev, b->scratch), "phyamd_set_rate_matrix");
@@ -241,7 +254,7 @@ static void push_model(binding *b, bool all_nodes) {
 	}
 	const double *freqs = tlk->get_root_frequencies(tlk);
 	if (full || memcmp(freqs, b->freqs, sizeof(double) * S)) {
-		memcpy(b->freqs, freqs, sizeof(double) * S);
+		memcpy(b->freqs, freqs, sizeof(double) * S); /* (entries S .. Sp-1 stay 0) */
 		die_on(phyamd_set_frequencies(b->dev, b->freqs), "phyamd_set_frequencies");
 	}
 
@@ -369,7 +382,7 @@ static size_t subst_parameter_count(const SubstitutionModel *m, size_t *rate_cou
 static bool wants_substitution_gradient(const binding *b) {
 	const SingleTreeLikelihood *tlk = b->tlk;
 	const int f = tlk->prepared_gradient;
-	if (tlk->m->dPdp == NULL || tlk->m->modeltype == NONREVERSIBLE) return false;
+	if (tlk->m->dPdp == NULL) return false;
 	if (f & (TREELIKELIHOOD_FLAG_SUBSTITUTION_MODEL_UNCONSTRAINED | TREELIKELIHOOD_FLAG_SUBSTITUTION_MODEL)) return true;
 	if (f & (TREELIKELIHOOD_FLAG_SUBSTITUTION_MODEL_RATES | TREELIKELIHOOD_FLAG_SUBSTITUTION_MODEL_FREQUENCIES)) {
 		const double eps = b->model ? ((Model **)b->model->data)[1]->epsilon : 0.0; /* :3308: finite differences when epsilon > 0 */
@@ -391,12 +404,38 @@ static void device_parameter_gradient(binding *b, double *cat_gradient) {
 		b->np = np;
 	}
 	if (!b->dq_sent) { /* np calls of m->dPdp: once per parameter change, not once per gradient */
-		double *dQ = malloc(sizeof(double) * np * S * S);
+		const int Sp = b->Sp;
+		double *dQ = calloc(np * (size_t)Sp * Sp, sizeof(double)); /* rows and columns of the padding states stay 0 */
 		for (size_t p = 0; p < np; p++) {
 			/* m->dQ after the first half of m->dPdp (_gtr_dQdp, _hky_dQdp, _general_dQdp) is d(normalised Q)/d(parameter p) */
 			m->dQ_need_update = true;
 			m->dPdp(m, (int)p, b->scratch, 0.1);
-			memcpy(dQ + p * S * S, m->dQ, sizeof(double) * S * S);
+			const double *src = m->dQ;
+			if (m->modeltype == REVERSIBLE || m->modeltype == NONREVERSIBLE) {
+				/* the general model's dPdp leaves m->dQ rotated into its eigen basis, U^-1 dQ U (gensubst.c:308-319; the nucleotide
+				 * models keep dQ itself, substmodel.c:469-489): rotate it back, the engine takes dQ */
+				double *tmp = b->scratch, *raw = b->scratch + (size_t)S * S;
+				double **U = m->eigendcmp->evec, **Ui = m->eigendcmp->Invevec;
+				for (int i = 0; i < S; i++)
+					for (int j = 0; j < S; j++) {
+						double v = 0.0;
+						for (int k = 0; k < S; k++) v += U[i][k] * m->dQ[(size_t)k * S + j];
+						tmp[(size_t)i * S + j] = v;
+					}
+				for (int i = 0; i < S; i++)
+					for (int j = 0; j < S; j++) {
+						double v = 0.0;
+						for (int k = 0; k < S; k++) v += tmp[(size_t)i * S + k] * Ui[k][j];
+						raw[(size_t)i * S + j] = v;
+					}
+				src = raw;
+			}
+			for (int i = 0; i < S; i++) memcpy(dQ + p * Sp * Sp + (size_t)i * Sp, src + (size_t)i * S, sizeof(double) * S);
+			if (getenv("PHYSHER_DEVICE_DEBUG")) {
+				fprintf(stderr, "dQ[%zu] (modeltype %d):", p, (int)m->modeltype);
+				for (int i = 0; i < S * S; i++) fprintf(stderr, " %.10g", src[i]);
+				fprintf(stderr, "\n");
+			}
 		}
 		m->dQ_need_update = true;
 		die_on(phyamd_set_rate_matrix_derivatives(b->dev, (int)np, dQ), "phyamd_set_rate_matrix_derivatives");
@@ -572,8 +611,8 @@ static void _store_device(Model *self) {
 	keep_copy(&b->st_bl, b->bl, b->N);
 	keep_copy(&b->st_rates, b->rates, b->C);
 	keep_copy(&b->st_props, b->props, b->C);
-	keep_copy(&b->st_freqs, b->freqs, S);
-	keep_copy(&b->st_eigen, b->eigen, S + 2 * S * S);
+	keep_copy(&b->st_freqs, b->freqs, b->Sp);
+	keep_copy(&b->st_eigen, b->eigen, (size_t)b->Sp + 2 * (size_t)b->Sp * b->Sp);
 	b->stored = true;
 	b->restore_pending = false;
 }
@@ -590,8 +629,8 @@ static void _handle_restore_device(Model *self, Model *model, int index) {
 	memcpy(b->bl, b->st_bl, sizeof(double) * b->N);
 	memcpy(b->rates, b->st_rates, sizeof(double) * b->C);
 	memcpy(b->props, b->st_props, sizeof(double) * b->C);
-	memcpy(b->freqs, b->st_freqs, sizeof(double) * S);
-	memcpy(b->eigen, b->st_eigen, sizeof(double) * (S + 2 * S * S));
+	memcpy(b->freqs, b->st_freqs, sizeof(double) * b->Sp);
+	memcpy(b->eigen, b->st_eigen, sizeof(double) * ((size_t)b->Sp + 2 * (size_t)b->Sp * b->Sp));
 	b->dq_sent = false;
 	b->restore_pending = true; /* cleared by the next store or evaluation; further sub-model restores of this cycle change nothing */
 	b->generation++;
@@ -625,8 +664,14 @@ int SingleTreeLikelihood_enable_device(SingleTreeLikelihood *tlk, Model *model, 
 	const char *ex = getenv("PHYSHER_DEVICE_EXACT");
 	b->exact = ex && atoi(ex) != 0;
 	const int N = b->N, S = b->S, C = b->C;
+	if (S > 61) {
+		fprintf(stderr, "physher device backend: %d states (more than 61) stay on the CPU kernels\n", S);
+		free(b);
+		return PHYAMD_EUNSUPPORTED;
+	}
+	const int Sp = b->Sp = S <= 4 ? 4 : S <= 20 ? 20 : S <= 60 ? 60 : 61;
 
-	phyamd_config cfg = {b->T, b->P, S, C, device_count >= 1 && device_ids ? device_ids[0] : -1, tlk->scale ? PHYAMD_RESCALE_ALWAYS : PHYAMD_RESCALE_AUTO, 0, NULL};
+	phyamd_config cfg = {b->T, b->P, Sp, C, device_count >= 1 && device_ids ? device_ids[0] : -1, tlk->scale ? PHYAMD_RESCALE_ALWAYS : PHYAMD_RESCALE_AUTO, 0, NULL};
 	b->rescale_sent = cfg.rescale;
 	int rc = device_count > 1 ? phyamd_create_sharded(&cfg, device_count, device_ids, &b->dev) : phyamd_create(&cfg, &b->dev);
 	if (rc != PHYAMD_OK) {
@@ -647,25 +692,39 @@ int SingleTreeLikelihood_enable_device(SingleTreeLikelihood *tlk, Model *model, 
 	die_on(phyamd_set_pattern_weights(b->dev, tlk->sp->weights), "phyamd_set_pattern_weights");
 	/* tips: state codes ("tipstates": true, kernels K3/K4) or the data type's 0/1 partials (treelikelihood.c:1094-1117) */
 	double *tmp = tlk->use_tip_states ? NULL : malloc(sizeof(double) * (size_t)b->P * S);
+	double *wide = !tlk->use_tip_states && Sp != S ? calloc((size_t)b->P * Sp, sizeof(double)) : NULL; /* padding states: partial 0 */
+	uint8_t *codes = tlk->use_tip_states && Sp != S ? malloc(b->P) : NULL;
 	for (int i = 0; i < N; i++) {
 		Node *n = Tree_node(tlk->tree, i);
 		if (!Node_isleaf(n)) continue;
 		const int seq = tlk->mapping[Node_id(n)];
-		if (tlk->use_tip_states) die_on(phyamd_set_tip_states(b->dev, Node_id(n), tlk->sp->patterns[seq]), "phyamd_set_tip_states");
-		else {
+		if (tlk->use_tip_states) {
+			const uint8_t *src = tlk->sp->patterns[seq];
+			if (codes) { /* a code >= S reads as "all states" (sitepattern.h:68-82): that is code Sp on the engine, not a padding state */
+				for (int k = 0; k < b->P; k++) codes[k] = src[k] >= S ? (uint8_t)Sp : src[k];
+				src = codes;
+			}
+			die_on(phyamd_set_tip_states(b->dev, Node_id(n), src), "phyamd_set_tip_states");
+		} else {
 			tlk->sp->get_partials(tlk->sp, seq, tmp);
-			die_on(phyamd_set_tip_partials(b->dev, Node_id(n), tmp), "phyamd_set_tip_partials");
+			if (wide) {
+				for (int k = 0; k < b->P; k++) memcpy(wide + (size_t)k * Sp, tmp + (size_t)k * S, sizeof(double) * S);
+				die_on(phyamd_set_tip_partials(b->dev, Node_id(n), wide), "phyamd_set_tip_partials");
+			} else
+				die_on(phyamd_set_tip_partials(b->dev, Node_id(n), tmp), "phyamd_set_tip_partials");
 		}
 	}
 	free(tmp);
+	free(wide);
+	free(codes);
 
 	b->bl = calloc(N, sizeof(double));
 	b->rates = calloc(C, sizeof(double));
 	b->props = calloc(C, sizeof(double));
-	b->freqs = calloc(S, sizeof(double));
-	b->eigen = calloc(S + 2 * S * S, sizeof(double));
-	b->rootf = calloc(S, sizeof(double));
-	b->scratch = calloc((size_t)S * S + 16, sizeof(double));
+	b->freqs = calloc(Sp, sizeof(double));
+	b->eigen = calloc((size_t)Sp + 2 * (size_t)Sp * Sp, sizeof(double));
+	b->rootf = calloc(Sp, sizeof(double));
+	b->scratch = calloc((size_t)2 * Sp * Sp + 16, sizeof(double));
 	b->own_eigen = new_EigenDecomposition(S);
 	/* (models with parameter derivatives -- HKY: dPdp -- stay on the eigen route: the engine differentiates U F(t) U^-1) */
 	b->closed_form = S == 4 && tlk->m->dPdp == NULL && (tlk->m->modeltype == JC69 || tlk->m->modeltype == K80 || (tlk->m->name && strcasecmp(tlk->m->name, "F81") == 0)) &&

@@ -61,6 +61,10 @@ CASES = [
     ("wag_g4_t60_rescale", dict(T=60, sites=40, seed=16, bl=(0.3, 0.9), datatype="aa", model="wag", categories=4, alpha=0.5, rescale=1, slim=1)),
     ("wag_g2_t500_autorescale", dict(T=500, sites=10, seed=17, bl=(0.5, 1.5), datatype="aa", model="wag", categories=2, alpha=0.5, slim=1)),
     ("mg94_t40_rescale", dict(T=40, sites=12, seed=18, bl=(0.3, 0.9), datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=1, rescale=1, slim=1)),
+    # the headline tree size, unscaled (branches short enough to stay above the underflow that switches rescaling on): the default
+    # chunked walks of the engine and the binding (integration/physher_device.c) against the reference at 1000 taxa
+    ("gtr_g4_t1000", dict(T=1000, sites=150, seed=19, bl=(0.004, 0.04), datatype="nucleotide", model="gtr", rates=GTR_RATES, freqs=GTR_FREQS, categories=4, alpha=0.5,
+                          tipstates=1, slim=1)),
     ("mg94_g2_t6_tipstates", dict(T=6, sites=30, seed=11, datatype="codon", model="mg94", rates="2.0,1.0,0.5", categories=2, alpha=0.8, tipstates=1)),
 ]
 

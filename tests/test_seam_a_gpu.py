@@ -96,6 +96,29 @@ def test_reference_object_graph_on_device_matches_cpu_fixture(case, tmp_path):
     close_where_finite(dev["gradient_all"], gold["gradient_all"], 1e-5 if lossy else 1e-8 * factor, "gradient_all", underflows=lossy or multi)
 
 
+TRAIT_CASES = sorted(d for d in os.listdir(GOLDEN) if os.path.isfile(os.path.join(GOLDEN, d, "trait_spec.txt")))
+
+
+@pytest.mark.parametrize("case", TRAIT_CASES)
+def test_state_counts_without_kernels_are_padded(case, tmp_path):
+    """Discrete-trait models (general data type: 2, 5 and 7 states, named ambiguity sets, with and without gamma categories) built by
+    the reference's own constructors (ref_driver attr = physher.cpp:53-75, 321-350, 594-629).  The engine has kernels for 4, 20,
+    60 and 61 states; the binding pads other counts with inert states, as the reference's generic kernels take any count
+    (treelikelihoodX.c:43-576): lnL and every gradient block must equal the CPU reference's."""
+    gold = load(case)
+    out_json = tmp_path / "device.json"
+    out = run([DRIVER, "attr", "trait_spec.txt", str(out_json)], os.path.join(GOLDEN, case), device_env(PHYSHER_DEVICE=1))
+    lik, grad, _ = device_work(out.stderr)
+    assert lik >= 1 and grad >= 1, (lik, grad)
+    with open(out_json) as f:
+        dev = json.load(f)
+    assert dev["state_count"] == gold["state_count"] and gold["state_count"] not in (4, 20, 60, 61)
+    assert abs(dev["lnl"] - gold["lnl"]) <= 1e-10 * abs(gold["lnl"]), (dev["lnl"], gold["lnl"])
+    np.testing.assert_allclose(np.array(dev["pattern_lk"]), gold["pattern_lk"], rtol=1e-10, atol=1e-10)
+    close_where_finite(dev["gradient_tree"], gold["gradient_tree"], 1e-9, "gradient_tree")
+    close_where_finite(dev["gradient_all"], gold["gradient_all"], 1e-8, "gradient_all")
+
+
 @pytest.mark.parametrize("case", ["jc69_t12", "gtr_g4_t16"])
 def test_brent_call_pattern_on_device(case, tmp_path):
     """The optimiser's fast path through the binding (serial_brent_optimize_tree's call pattern, optimizer.c:112-153; ref_driver
