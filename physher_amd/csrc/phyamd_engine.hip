@@ -116,6 +116,7 @@ struct NodeOp {
 #include "phyamd_walk4mx.inc"
 #include "phyamd_walk4s.inc"
 #include "phyamd_general.inc"
+#include "phyamd_genwalk.inc"
 #include "phyamd_patterns.inc"
 
 #include "phyamd_shard.inc"

@@ -6,8 +6,8 @@ TAG=${1:?tag}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/sq_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PHYAMD_BENCH_BLOCK=1000000
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs --no-distinct-check --steps 1 --warmup 1"
-KREGEX='k_(lower4|upper4)'
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs --no-distinct-check --steps 1 --warmup 1 $QSQ_ARGS"  # QSQ_ARGS: extra bench.py flags (e.g. --subst-gradient)
+KREGEX=${QSQ_KERNELS:-'k_(lower4|upper4)'}
 p=0
 for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES"; do
   p=$((p+1))
