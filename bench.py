@@ -32,9 +32,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 GTR_RATES = (1.2, 3.1, 0.7, 0.9, 2.8, 1.0)  # ac ag at cg ct gt
 GTR_FREQS = (0.3, 0.2, 0.2, 0.3)
 ALPHA = 0.5
-# the usual discrete-gamma(alpha = 0.5) 4-category rates (mean 1); the engine takes rates as inputs, so the
-# benchmark needs no host-side quantile code
-GAMMA4_RATES_05 = (0.03338775, 0.25191592, 0.82026848, 2.89442785)
+# physher's own discrete gamma(alpha = 0.5), 4 categories (quantile medians rescaled to mean 1: sitemodel.c / gamma.c; read off
+# `ref_driver dump`'s cat_rates): the engine takes rates as inputs, and the CPU baseline's lnL of the same sample is compared
+# with the engine's (cpu_baseline.lnl_check), so both must discretise alike
+GAMMA4_RATES_05 = (0.029077754761923313, 0.28071453713995315, 0.9247730651141549, 2.7654346429839682)
 
 
 def gtr_eigen():
@@ -107,43 +108,56 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
     driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     sub = states[:, :sp]
     if os.path.exists(driver):
+        # Three shards of the workload (its first, middle and last `sp` sites), one after the other on one core.  Whole shards of 1e5
+        # patterns are out of reach of a bounded baseline: one gradient evaluation of 1000 taxa x 1e5 patterns costs ~16 s on a core and
+        # the reference holds ~51 GB of partial arrays for it (2 x 1999 nodes x 1e5 x 16 doubles).
+        L = states.shape[1]
+        starts = sorted({0, max(0, (L - sp) // 2), max(0, L - sp)})
         with tempfile.TemporaryDirectory() as d:
-            with open(os.path.join(d, "aln.fa"), "w") as f:
-                f.write(synth.to_fasta(tree.names, sub, "nucleotide"))
             with open(os.path.join(d, "tree.nwk"), "w") as f:
                 f.write(tree.newick() + "\n")
-            with open(os.path.join(d, "spec.txt"), "w") as f:
-                f.write(f"fasta {d}/aln.fa\nnewick {d}/tree.nwk\ndatatype nucleotide\nmodel gtr\n"
-                        f"rates {','.join(map(str, GTR_RATES[:5]))}\nfreqs {','.join(map(str, GTR_FREQS))}\n"
-                        f"categories {len(cat_rates)}\nalpha {ALPHA}\ntipstates 0\nsse 1\n")
+            specs = []
+            for j, st in enumerate(starts):
+                with open(os.path.join(d, f"aln{j}.fa"), "w") as f:
+                    f.write(synth.to_fasta(tree.names, states[:, st:st + sp], "nucleotide"))
+                with open(os.path.join(d, f"spec{j}.txt"), "w") as f:
+                    f.write(f"fasta {d}/aln{j}.fa\nnewick {d}/tree.nwk\ndatatype nucleotide\nmodel gtr\n"
+                            f"rates {','.join(map(str, GTR_RATES[:5]))}\nfreqs {','.join(map(str, GTR_FREQS))}\n"
+                            f"categories {len(cat_rates)}\nalpha {ALPHA}\ntipstates 0\nsse 1\n")
+                specs.append(os.path.join(d, f"spec{j}.txt"))
             # one gradient evaluation costs 16-26 ns per (branch, pattern, category) per core; the driver also times as many
             # lnL-only evaluations (~40 % of that) and one warm-up of each
             est = 20e-9 * (2 * T - 2) * sp * len(cat_rates)
-            iters = max(3, min(40, int(budget_s / (1.5 * est))))
+            iters = max(2, min(40, int(budget_s / (1.5 * est * len(specs)))))
             try:
-                out = subprocess.run([driver, "bench", os.path.join(d, "spec.txt"), str(iters), "1"], capture_output=True, text=True,
-                                     timeout=max(120, 20 * budget_s), check=True).stdout
-                r = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
-                compressed = r["patterns"]
-                t_eval = r["grad_ms_per_eval"] / 1e3
+                runs = []
+                for spec in specs:
+                    out = subprocess.run([driver, "bench", spec, str(iters), "1"], capture_output=True, text=True,
+                                         timeout=max(120, 20 * budget_s), check=True).stdout
+                    runs.append(json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1]))
+                r = runs[0]
+                compressed = sum(x["patterns"] for x in runs) / len(runs)
+                t_eval = sum(x["grad_ms_per_eval"] for x in runs) / len(runs) / 1e3
                 # physher has no threading inside one likelihood: the host's full capability is K independent
-                # instances, each owning a share of the patterns -- timed here as K concurrent copies of the same sample
+                # instances, each owning a share of the patterns -- timed here as K concurrent copies of the first shard
                 multi = None
                 try:
                     K = max(1, min(len(os.sched_getaffinity(0)), 16))  # a one-GPU share of the host
                     if K > 1:
-                        it2 = max(2, iters // 3)
-                        procs = [subprocess.Popen([driver, "bench", os.path.join(d, "spec.txt"), str(it2), "1"], stdout=subprocess.PIPE, text=True)
+                        it2 = max(2, iters // 2)
+                        procs = [subprocess.Popen([driver, "bench", specs[0], str(it2), "1"], stdout=subprocess.PIPE, text=True)
                                  for _ in range(K)]
                         outs = [pr.communicate(timeout=max(180, 30 * budget_s))[0] for pr in procs]
                         ts = [json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1])["grad_ms_per_eval"] / 1e3 for o in outs]
-                        multi = dict(cores=K, patterns_per_second=sum(compressed / t for t in ts), slowest_t_eval=max(ts), iters=it2)
+                        multi = dict(cores=K, patterns_per_second=sum(r["patterns"] / t for t in ts), slowest_t_eval=max(ts), iters=it2)
                 except Exception as exc:
                     print(f"[bench] concurrent CPU timing skipped ({exc})", file=sys.stderr)
                 return dict(kind="reference", cores=1, t_eval=t_eval, patterns=compressed, iters=iters, lnl_ms=r["lnl_ms_per_eval"], multi=multi, lnl=r.get("lnl"),
-                            sample=f"physher SSE path (oracle/_ref/ref_driver bench), {T} taxa x {compressed} patterns "
-                                   f"(first {sp} sites of the workload: a cache-resident sample, which flatters the CPU), {iters} gradient evals after 1 warm-up, "
-                                   f"scaled linearly to the full pattern count")
+                            shards=[dict(first_site=st, patterns=x["patterns"], seconds_per_eval=x["grad_ms_per_eval"] / 1e3) for st, x in zip(starts, runs)],
+                            sample=f"physher SSE path (oracle/_ref/ref_driver bench), {T} taxa, {len(runs)} shards of {sp} sites (first, middle and last of the "
+                                   f"workload; {int(compressed)} patterns each on average), {iters} gradient evals per shard after 1 warm-up, one core, mean "
+                                   f"seconds per evaluation scaled linearly to the full pattern count; whole 1e5-pattern shards are not timed: ~16 s per "
+                                   f"evaluation and ~51 GB of host memory each")
             except Exception as exc:  # fall through to the port, but say why
                 print(f"[bench] reference driver failed ({exc}); timing the CPU port instead", file=sys.stderr)
     from oracle import phyoracle as po
@@ -502,6 +516,15 @@ def main():
             valu_s = valu_insts * launches * 4.0 / (1024 * 2.4e9)
             valu = {"wave_instructions_per_launch": valu_insts, "busy_frac": valu_s / upper_s,
                     "note": "VALU wave-instructions (PMC SQ_INSTS_VALU) x 4 cycles / (1024 SIMDs x 2.4 GHz) / kernel time"}
+            # every instruction class counts against a SIMD's issue rate (both walks are bound by it): all wave-instructions
+            # of the launch against the SIMD-cycles it took
+            every = sum(tj.get(f"upper_{k}_insts_per_launch") or 0 for k in ("valu", "salu", "smem", "lds"))
+            if every > valu_insts:
+                valu["all_wave_instructions_per_launch"] = every
+                valu["simd_cycles_per_instruction"] = upper_s / launches * 1024 * 2.4e9 / every
+        upper_kernel = ((tj.get("kernels") or {}).get("upper") or {}).get("kernel") if traffic is not None else None
+        if not upper_kernel:  # (the streamed walk runs plain and rescaled 4-state evaluations with <= 4 categories and one pattern tile)
+            upper_kernel = "k_upper4_stream" if kern == "4_walk" and C <= 4 and p["tiles"] == 1 and not os.environ.get("PHYAMD_WALK_STREAM") == "0" else f"k_upper{kern}"
         workload_label = f"{T}-taxon {wl['name'].split(' (')[0]} fp64, {P:.0e} site patterns".replace("e+0", "e").replace("e+", "e")
         out = {
             "metric": ("lnL+gradient evals/sec, 1000-taxon GTR+G4 fp64, 1e6 site patterns" if (args.config == "cfg5" and T == 1000 and P == 1_000_000 and C == 4)
@@ -526,7 +549,7 @@ def main():
                                        f"{world} process(es), one per GPU" + ("" if world == 1 else (", one all-gather + pairwise sum" if args.deterministic_sum else ", one RCCL all-reduce"))),
                        "taxa": T, "patterns": P, "categories": C, "states": S, "patterns_per_gpu": Pl // args.gpus if single else Pl, "lnL": lnl,
                        "rescaling": eng.rescaling, "device_bytes": p["device_bytes"], "tiles": p["tiles"]},
-            "roofline": {"bound": "hbm", "kernel": f"k_upper{kern} (pre-order pass + fused branch gradient)",
+            "roofline": {"bound": "hbm", "kernel": f"{upper_kernel} (pre-order pass + fused branch gradient)",
                          # achieved / frac: MEASURED HBM bytes of the launch (PMC, per the guide's FETCH_SIZE / WRITE_SIZE recipe)
                          # over the live HIP-event time of the same kernel; null when no PMC file matches this shape
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -561,6 +584,8 @@ def main():
             scaled = cb["t_eval"] * (P / cb["patterns"])
             out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "evals/s", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
                                    "sample_seconds_per_eval": cb["t_eval"], "sample_patterns": cb["patterns"]}
+            if cb.get("shards"):
+                out["cpu_baseline"]["shards"] = cb["shards"]
             if cb.get("lnl") is not None:
                 # the same sample (the first sites of the workload, every site with weight 1) through the engine: the reference's lnL of
                 # the driver's own run is the yardstick (relative difference; the parity tests hold 1e-10)
@@ -577,6 +602,8 @@ def main():
                     lnl_gpu = chk.log_likelihood()
                 rel = abs(lnl_gpu - cb["lnl"]) / abs(cb["lnl"])
                 out["cpu_baseline"]["lnl_check"] = {"lnL_reference": cb["lnl"], "lnL_engine": lnl_gpu, "relative_difference": rel, "within_1e-10": bool(rel <= 1e-10)}
+                if rel > 1e-10:
+                    print(f"[bench] WARNING: the engine's lnL of the CPU baseline's first shard differs from the reference's by {rel:.3e} (relative)", file=sys.stderr)
             if cb.get("multi"):  # every host core busy with its own pattern shard (the reference's only way to use them)
                 m = cb["multi"]
                 out["cpu_baseline"]["all_cores"] = {"value": m["patterns_per_second"] / P, "unit": "evals/s", "cores": m["cores"],

@@ -41,6 +41,7 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM
 	echo "$name done" >&2
 done
 cd "$ROOT"
+python3 profiles/kernel_resources.py > "$OUT/${TAG}_kernel_resources.json"
 PMC_LOWER_LAUNCHES=2 python3 profiles/pmc_traffic.py "$TAG" "$OUT/${TAG}_pmc_FETCH_SIZE.csv" "$OUT/${TAG}_pmc_WRITE_SIZE.csv" 1000 1000000 4 2 "$OUT/${TAG}_traffic.json" "$OUT/${TAG}_pmc_SQ_INSTS_VALU.csv" > /dev/null
 # the bench line of the SAME binary with the measured roofline: the traffic file carries the library's sha256, bench.py refuses another build's
 unset PHYAMD_BENCH_BLOCK

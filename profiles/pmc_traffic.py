@@ -31,11 +31,22 @@ def library_hash():
 
 
 def kernel_resources(fn, key):
-    """registers and LDS of the kernel's launches as the profiler saw them"""
+    """registers, spills and scratch of the kernel that ran (its name from the profiler's rows), read from the code object of the
+    profiled library by profiles/kernel_resources.py; workgroup size as the profiler saw the launch"""
+    import re
+    import subprocess
     for r in csv.DictReader(open(fn)):
         if key in r["Kernel_Name"]:
-            return {"kernel": r["Kernel_Name"].split("(")[0].split("::")[-1].strip(), "vgpr": int(r["VGPR_Count"]), "accum_vgpr": int(r["Accum_VGPR_Count"]),
-                    "sgpr": int(r["SGPR_Count"]), "lds_bytes": int(r["LDS_Block_Size"]), "workgroup": int(r["Workgroup_Size"])}
+            m = re.search(r"(k_\w+(?:<[^>]*>)?)", r["Kernel_Name"])
+            name = m.group(1) if m else r["Kernel_Name"]
+            here = os.path.dirname(os.path.abspath(__file__))
+            try:
+                table = json.loads(subprocess.run([sys.executable, os.path.join(here, "kernel_resources.py"), "k_"], check=True, capture_output=True, text=True).stdout)["kernels"]
+            except Exception as exc:  # (llvm tools missing: keep the name)
+                return {"kernel": name, "error": str(exc)}
+            res = dict(table.get(name, {}))
+            res.update({"kernel": name, "workgroup": int(r["Workgroup_Size"])})
+            return res
     return None
 
 
