@@ -522,6 +522,9 @@ def main():
             if every > valu_insts:
                 valu["all_wave_instructions_per_launch"] = every
                 valu["simd_cycles_per_instruction"] = upper_s / launches * 1024 * 2.4e9 / every
+                # a SIMD has one issue slot every 4 cycles; no variant of either walk has been seen to issue faster than one
+                # instruction per slot, so this is the fraction of that (empirical) roof
+                valu["issue_slot_frac"] = 4.0 / valu["simd_cycles_per_instruction"]
         upper_kernel = ((tj.get("kernels") or {}).get("upper") or {}).get("kernel") if traffic is not None else None
         if not upper_kernel:  # (the streamed walk runs plain and rescaled 4-state evaluations with <= 4 categories and one pattern tile)
             upper_kernel = "k_upper4_stream" if kern == "4_walk" and C <= 4 and p["tiles"] == 1 and not os.environ.get("PHYAMD_WALK_STREAM") == "0" else f"k_upper{kern}"
