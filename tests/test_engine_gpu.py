@@ -486,6 +486,34 @@ def test_generic_states_forced_rescaling(S, T, P, C):
     _compare_with_oracle(pb, RESCALE_ALWAYS, flags=GRAD_FOLD_ROOT_FREQS)
 
 
+@pytest.mark.parametrize("T,P,C,shape,rescale", [(40, 130, 4, "random", RESCALE_NEVER), (300, 70, 4, "random", RESCALE_NEVER), (120, 65, 2, "caterpillar", RESCALE_NEVER),
+                                                 (1000, 64, 4, "random", RESCALE_NEVER), (200, 90, 4, "random", RESCALE_ALWAYS)])
+def test_nucleotide_ambiguity_codes_in_the_streamed_walk(T, P, C, shape, rescale):
+    """IUPAC-style partial ambiguity masks (R, Y, ... : two or three of the four states) at 4 states: the streamed pre-order walk
+    keeps five rows per tip and forms such a tip's rows as the sum of its states' rows (k_upper4_stream<.., AMBIG>,
+    SX::tip_rows).  One tip cell in eight carries one of the ten partial masks, some are unknown; lnL, the stored partials
+    and the gradient against the oracle on the same 0/1 tip vectors, for the default engine and for the table-gather walk."""
+    forced = rescale == RESCALE_ALWAYS
+    pb = random_problem(T, P, C, seed=4100 + T, shape=shape, gaps=0.03, bl=(0.2, 0.6) if forced else (0.01, 0.1), rescale=1 if forced else 0)
+    rng = np.random.default_rng(T * 7 + P)
+    masks = [m for m in range(1, 15) if bin(m).count("1") in (2, 3)]
+    assert len(masks) == 10
+    tp = np.zeros((T, P, 4))
+    for t in range(T):
+        for k in range(P):
+            code = pb.tip_states[t, k]
+            if code >= 4:
+                tp[t, k, :] = 1.0
+            elif rng.random() < 0.125:
+                m = masks[rng.integers(10)] | (1 << int(code))  # keep the observed state possible
+                tp[t, k, :] = [(m >> i) & 1 for i in range(4)]
+            else:
+                tp[t, k, code] = 1.0
+    pb2 = po.Problem(pb.left, pb.right, pb.root, pb.weights, pb.eval, pb.evec, pb.ivec, pb.freqs, pb.cat_rates, pb.cat_props,
+                     pb.branch_lengths, tip_states=pb.tip_states, tip_partials=tp, rescale=1 if forced else 0)
+    _compare_with_oracle(pb2, rescale, tip_mode="partials", check_partials=not forced)
+
+
 @pytest.mark.parametrize("S,T,P,C,rescale", [(20, 14, 150, 2, RESCALE_NEVER), (61, 9, 40, 1, RESCALE_NEVER), (20, 50, 70, 2, RESCALE_ALWAYS)])
 def test_generic_states_ambiguity_sets(S, T, P, C, rescale):
     """Tip partials that are sets of states (named ambiguities of a general data type, datatype.c:212-262) on the MFMA
