@@ -1,0 +1,38 @@
+"""The hot kernels' register budgets, read from the code object of the built library (profiles/kernel_resources.py): the
+occupancies DESIGN.md section 3 relies on -- four waves per SIMD for the streamed pre-order walk (<= 128 registers, nothing
+spilled), seven for the post-order walk (<= 72), four for the 20-state walk -- are a build-time property, checked without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "physher_amd", "libphysher_amd.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(LLVM, "llvm-readelf")):
+        pytest.skip("built library or llvm tools missing")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "kernel_resources.py"), "k_"], check=True, capture_output=True, text=True).stdout
+    table = json.loads(out)
+    assert len(table["library_sha256"]) == 64
+    return table["kernels"]
+
+
+@pytest.mark.parametrize("name,max_vgpr", [("k_upper4_stream<false, false, false>", 128), ("k_upper4_stream<true, false, false>", 128),
+                                           ("k_lower4_walk<4, 1, false, true>", 72), ("k_lower_gen_walk<2, 5>", 128)])
+def test_hot_kernels_keep_their_occupancy(kernels, name, max_vgpr):
+    k = kernels[name]
+    assert k["vgpr_count"] <= max_vgpr, k
+    assert k["vgpr_spill_count"] == 0 and k["scratch_bytes"] == 0, k
+
+
+def test_every_streamed_variant_is_in_the_library(kernels):
+    for fold in ("false", "true"):
+        for scale in ("false", "true"):
+            for ambig in ("false", "true"):
+                assert f"k_upper4_stream<{fold}, {scale}, {ambig}>" in kernels
