@@ -528,6 +528,10 @@ def main():
         upper_kernel = ((tj.get("kernels") or {}).get("upper") or {}).get("kernel") if traffic is not None else None
         if not upper_kernel:  # (the streamed walk runs plain and rescaled 4-state evaluations with <= 4 categories and one pattern tile)
             upper_kernel = "k_upper4_stream" if kern == "4_walk" and C <= 4 and p["tiles"] == 1 and not os.environ.get("PHYAMD_WALK_STREAM") == "0" else f"k_upper{kern}"
+        lower_kernel = ((tj.get("kernels") or {}).get("lower") or {}).get("kernel") if traffic is not None else None
+        if not lower_kernel:  # (the streamed post-order walk runs plain 4-state evaluations with <= 4 categories)
+            lower_kernel = ("k_lower4_stream" if kern == "4_walk" and C <= 4 and not eng.rescaling and os.environ.get("PHYAMD_LOWER_STREAM") != "0" else
+                            (f"k_lower{kern}" if p["lower_launches"] <= 2 or S != 4 else "k_lower4"))
         workload_label = f"{T}-taxon {wl['name'].split(' (')[0]} fp64, {P:.0e} site patterns".replace("e+0", "e").replace("e+", "e")
         out = {
             "metric": ("lnL+gradient evals/sec, 1000-taxon GTR+G4 fp64, 1e6 site patterns" if (args.config == "cfg5" and T == 1000 and P == 1_000_000 and C == 4)
@@ -565,7 +569,7 @@ def main():
                                           {"GB/s": three_pass, "ratio_to_hbm_peak": three_pass / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": upper_b / launches},
                          "launches_per_eval": launches,
                          "avg_launch_ms": prof["upper_ms"] / launches,
-                         "lower_kernel": {"kernel": f"k_lower{kern}" if p["lower_launches"] <= 2 or S != 4 else "k_lower4",
+                         "lower_kernel": {"kernel": lower_kernel,
                                           "launches_per_eval": p["lower_launches"], "ms_per_eval": prof["lower_ms"]},
                          "ms_per_eval": {k: prof[k] for k in prof}},
         }
