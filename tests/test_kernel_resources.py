@@ -1,6 +1,6 @@
 """The hot kernels' register budgets, read from the code object of the built library (profiles/kernel_resources.py): the
 occupancies DESIGN.md section 3 relies on -- four waves per SIMD for the streamed pre-order walk (<= 128 registers, nothing
-spilled), seven for the post-order walk (<= 72), four for the 20-state walk -- are a build-time property, checked without a GPU."""
+spilled), six for the streamed post-order walk (<= 80), seven for the table-gather one (<= 72), four for the 20-state walk -- are a build-time property, checked without a GPU."""
 import json
 import os
 import subprocess
@@ -24,7 +24,7 @@ def kernels():
 
 
 @pytest.mark.parametrize("name,max_vgpr", [("k_upper4_stream<false, false, false>", 128), ("k_upper4_stream<true, false, false>", 128),
-                                           ("k_lower4_walk<4, 1, false, true>", 72), ("k_lower_gen_walk<2, 5>", 128)])
+                                           ("k_lower4_stream<false, false>", 80), ("k_lower4_walk<4, 1, false, true>", 72), ("k_lower_gen_walk<2, 5>", 128)])
 def test_hot_kernels_keep_their_occupancy(kernels, name, max_vgpr):
     k = kernels[name]
     assert k["vgpr_count"] <= max_vgpr, k
