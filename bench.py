@@ -131,10 +131,13 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
             iters = max(2, min(40, int(budget_s / (1.5 * est * len(specs)))))
             try:
                 runs = []
-                for spec in specs:
-                    out = subprocess.run([driver, "bench", spec, str(iters), "1"], capture_output=True, text=True,
+                for j, spec in enumerate(specs):
+                    det_path = os.path.join(d, f"details{j}.json")
+                    out = subprocess.run([driver, "bench", spec, str(iters), "1", det_path], capture_output=True, text=True,
                                          timeout=max(120, 20 * budget_s), check=True).stdout
                     runs.append(json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1]))
+                    with open(det_path) as f:  # the gradient vector, per-pattern lnL and compressed patterns of the timed protocol
+                        runs[-1]["details"] = json.load(f)
                 r = runs[0]
                 compressed = sum(x["patterns"] for x in runs) / len(runs)
                 t_eval = sum(x["grad_ms_per_eval"] for x in runs) / len(runs) / 1e3
@@ -153,7 +156,8 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
                 except Exception as exc:
                     print(f"[bench] concurrent CPU timing skipped ({exc})", file=sys.stderr)
                 return dict(kind="reference", cores=1, t_eval=t_eval, patterns=compressed, iters=iters, lnl_ms=r["lnl_ms_per_eval"], multi=multi, lnl=r.get("lnl"),
-                            shards=[dict(first_site=st, patterns=x["patterns"], seconds_per_eval=x["grad_ms_per_eval"] / 1e3) for st, x in zip(starts, runs)],
+                            shards=[dict(first_site=st, patterns=x["patterns"], seconds_per_eval=x["grad_ms_per_eval"] / 1e3, details=x.get("details"))
+                                    for st, x in zip(starts, runs)],
                             sample=f"physher SSE path (oracle/_ref/ref_driver bench), {T} taxa, {len(runs)} shards of {sp} sites (first, middle and last of the "
                                    f"workload; {int(compressed)} patterns each on average), {iters} gradient evals per shard after 1 warm-up, one core, mean "
                                    f"seconds per evaluation scaled linearly to the full pattern count; whole 1e5-pattern shards are not timed: ~16 s per "
@@ -169,6 +173,101 @@ def cpu_baseline(tree, states, weights, cat_rates, sample_patterns, budget_s):
     t_eval = time.perf_counter() - t0
     return dict(kind="port", cores=1, t_eval=t_eval, patterns=sp, iters=1, lnl_ms=None,
                 sample=f"scalar CPU port (oracle/phyoracle.c), {T} taxa x {sp} patterns, 1 evaluation, scaled linearly")
+
+
+def reference_node_map(tree, details):
+    """bench node id -> the reference's node id, by clade (both trees come from the same Newick string; the reference numbers
+    its nodes while parsing).  Returns (ref_of [N], the reference's right-of-root node: it reports 0 for that branch and the
+    sum on its sibling, treelikelihood.c:3249-3255)."""
+    tip_of = {name: i for i, name in enumerate(tree.names)}
+    nodes = {nd["id"]: nd for nd in details["nodes"]}
+    ref_clade = {}
+    order, stack = [], [details["root"]]
+    while stack:
+        i = stack.pop()
+        order.append(i)
+        if nodes[i]["left"] >= 0:
+            stack += [nodes[i]["left"], nodes[i]["right"]]
+    for i in reversed(order):
+        nd = nodes[i]
+        ref_clade[i] = frozenset([tip_of[nd["name"]]]) if nd["left"] < 0 else ref_clade[nd["left"]] | ref_clade[nd["right"]]
+    by_clade = {c: i for i, c in ref_clade.items()}
+    N = tree.node_count
+    clade = [None] * N
+    order, stack = [], [int(tree.root)]
+    while stack:
+        i = stack.pop()
+        order.append(i)
+        if tree.left[i] >= 0:
+            stack += [int(tree.left[i]), int(tree.right[i])]
+    ref_of = np.full(N, -1, dtype=np.int64)
+    for i in reversed(order):
+        clade[i] = frozenset([i]) if tree.left[i] < 0 else clade[int(tree.left[i])] | clade[int(tree.right[i])]
+        ref_of[i] = by_clade[clade[i]]
+    return ref_of, nodes[details["root"]]["right"]
+
+
+def reference_site_map(tree, details, states_slice):
+    """site of the slice -> index of its column among the reference's compressed patterns (hash-table order)"""
+    tip_of = {name: i for i, name in enumerate(tree.names)}
+    rows = np.stack([np.frombuffer(r.encode(), dtype=np.uint8) - ord("0") for r in details["patterns"]])
+    pat = np.empty_like(rows)
+    for r, name in enumerate(details["taxa"]):
+        pat[tip_of[name]] = rows[r]
+    index = {pat[:, k].tobytes(): k for k in range(pat.shape[1])}
+    cols = np.ascontiguousarray(states_slice.T)
+    return np.array([index[cols[j].tobytes()] for j in range(cols.shape[0])], dtype=np.int64)
+
+
+def check_against_reference(eng, tree, states, weights, shards, cat_rates, cat_props, plk_all):
+    """Hold the TIMED engine (same object, same 1e6-pattern launches) against what the reference computed for the CPU baseline's
+    shards (ref_driver bench ... details: examples/benchmarking.c:485-503 protocol):
+      (i)  its per-pattern lnL of the last timed evaluation on each shard's sites (rtol 1e-11);
+      (ii) its branch gradient of each shard -- pattern weights 1 on the shard's sites and 0 elsewhere, so that the full-size pass
+           yields the shard's gradient -- against the reference's TreeLikelihood_gradient vector, node by node through the clade
+           map (1e-9 * max(1, |g|_inf)), and the shard's lnL (1e-10 relative).  The reference's TREE_MODEL-only gradient folds
+           the root frequencies into the uppers (treelikelihood.c:241, 2147-2153): the engine runs the same
+           convention here (GRAD_FOLD_ROOT_FREQS).
+    Returns the gradient_check object of the bench line."""
+    from physher_amd.engine import GRAD_FOLD_ROOT_FREQS
+    from physher_amd.sharding import epilogue
+    N = tree.node_count
+    out = {"shards": [], "per_pattern_lnl_rtol": 1e-11, "gradient_tol": "1e-9 * max(1, |g|_inf)", "lnl_rtol": 1e-10,
+           "what": "the timed engine's per-pattern lnL and (pattern weights 1 on the shard, 0 elsewhere) its branch gradient, against the "
+                   "reference's own values for the cpu_baseline shards (TreeLikelihood_gradient, TREE_MODEL flag; root-frequency folding as the reference does it)"}
+    ok = True
+    try:
+        for sh in shards:
+            det, st = sh["details"], sh["first_site"]
+            sp = int(round(sum(det["weights"])))
+            idx = reference_site_map(tree, det, states[:, st:st + sp])
+            ref_plk = np.array(det["pattern_lk"])[idx]
+            plk_err = float(np.max(np.abs(plk_all[st:st + sp] - ref_plk) / np.maximum(1e-300, np.abs(ref_plk))))
+            w = np.zeros(states.shape[1])
+            w[st:st + sp] = 1.0
+            eng.set_pattern_weights(w)
+            ref_of, ref_zero = reference_node_map(tree, det)
+            # the reference's own branch lengths: reading the rooted Newick as an unrooted tree it moves the root's right branch onto
+            # the left one (same lnL), and its folded gradient -- unlike the exact one -- depends on where that length sits
+            ref_nodes = {nd["id"]: nd for nd in det["nodes"]}
+            eng.set_branch_lengths(np.array([0.0 if n == tree.root else ref_nodes[int(ref_of[n])]["distance"] for n in range(N)]))
+            lnl, cg = eng.gradient(GRAD_FOLD_ROOT_FREQS)
+            _, g = epilogue(np.concatenate([[lnl], cg.reshape(-1)]), N, cat_rates, cat_props)
+            ref_g = np.array(det["gradient"])
+            keep = np.array([n != tree.root and ref_of[n] != ref_zero for n in range(N)])
+            gerr = float(np.max(np.abs(g[keep] - ref_g[ref_of[keep]])))
+            gmax = float(np.max(np.abs(ref_g[ref_of[keep]])))
+            lerr = abs(lnl - det["lnl"]) / abs(det["lnl"])
+            good = plk_err <= 1e-11 and gerr <= 1e-9 * max(1.0, gmax) and lerr <= 1e-10
+            ok = ok and good
+            out["shards"].append({"first_site": st, "sites": sp, "reference_patterns": len(det["weights"]), "per_pattern_lnl_max_rel_err": plk_err,
+                                  "gradient_max_abs_err": gerr, "gradient_inf_norm": gmax, "branches_compared": int(keep.sum()),
+                                  "lnl_rel_err": lerr, "ok": bool(good)})
+    finally:
+        eng.set_pattern_weights(weights)
+        eng.set_branch_lengths(tree.length)
+    out["ok"] = bool(ok)
+    return out
 
 
 def count_distinct_patterns(states):
@@ -207,7 +306,50 @@ def category_rates(C):
     return r / r.mean(), np.full(C, 1.0 / C)
 
 
-def time_other_config(config, device, stream, seed, evals):
+def generic_counters(path):
+    """profiles/generic_latest.json (profiles/collect_generic.sh) if it describes the loaded build of the library, else (None, why)"""
+    import hashlib
+    if not os.path.exists(path):
+        return None, "no counter profile (profiles/generic_latest.json)"
+    try:
+        with open(path) as f:
+            gj = json.load(f)
+        with open(os.path.join(ROOT, "physher_amd", "libphysher_amd.so"), "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest() != gj.get("library_sha256"):
+                return None, f"the counter profile ({gj.get('tag')}) was collected with another build of libphysher_amd.so: re-run profiles/collect_generic.sh"
+        return gj, None
+    except Exception as exc:
+        return None, f"counter profile unreadable: {exc}"
+
+
+def mfma_object(config, T, P, C, S, kernel_s, generic_json):
+    """The matrix-core side of a 20- / 61-state workload.  Counter-based (sha-tied profile): busy_frac = SQ_VALU_MFMA_BUSY_CYCLES per
+    evaluation / 1024 SIMDs / (kernel time x 2.4 GHz: the nominal clock -- under sustained f64 MFMA load the part holds ~2.05 GHz, so
+    the pipe's true occupancy is up to 17 % higher); issued flops from the instruction counters (tip children skip the MFMA: a
+    gathered column / row sums); HBM bytes from FETCH_SIZE / WRITE_SIZE.  vs_algorithmic_flops is SURVEY 8(d)'s per-node flop count
+    over the same time: a ratio against the spec-sheet peak, NOT a utilisation (it counts tip products the kernels never issue)."""
+    fl = algorithmic_flops(T, P, C, S)
+    tf = fl / kernel_s / 1e12
+    out = {"vs_algorithmic_flops": {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "ratio": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": fl},
+           "busy_frac": None, "issued_flops_per_eval": None, "issued_tflops": None, "hbm": None, "pmc_profile": None, "pmc_note": None}
+    gj, why = generic_counters(generic_json)
+    if gj is None or not gj.get(config):
+        out["pmc_note"] = why or f"the counter profile holds no {config}"
+        return out
+    g = gj[config]
+    out["pmc_profile"] = gj.get("tag")
+    if g.get("mfma_busy_cycles_per_eval"):
+        out["busy_frac"] = g["mfma_busy_cycles_per_eval"] / 1024.0 / (kernel_s * 2.4e9)
+    if g.get("mfma_f64_mops_per_eval"):  # one MOP = 512 flops (a v_mfma_f64_4x4x4_4b; a 16x16x4 is four)
+        out["issued_flops_per_eval"] = 512.0 * g["mfma_f64_mops_per_eval"]
+        out["issued_tflops"] = out["issued_flops_per_eval"] / kernel_s / 1e12
+    if g.get("hbm_bytes_per_eval"):
+        gbs = g["hbm_bytes_per_eval"] / kernel_s / 1e9
+        out["hbm"] = {"bytes_per_eval": g["hbm_bytes_per_eval"], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    return out
+
+
+def time_other_config(config, device, stream, seed, evals, generic_json=None):
     """One of BASELINE.json's smaller configurations (cfg2..cfg4) on the same GPU: ms per lnL + gradient evaluation with full
     recompute, timed around synchronous calls (result on the host), plus the engine's HIP-event split."""
     import torch
@@ -247,9 +389,7 @@ def time_other_config(config, device, stream, seed, evals):
            "evals_per_s": 1.0 / dt, "ms_per_eval": 1e3 * dt, "lower_ms": lower / evals, "upper_ms": upper / evals, "lnL": lnl,
            "rescaling": eng.rescaling, "evals": evals}
     if S != 4:
-        fl = algorithmic_flops(T, P, C, S)
-        tf = fl / ((lower + upper) / evals * 1e-3) / 1e12
-        out["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": fl}
+        out["mfma"] = mfma_object(config, T, P, C, S, (lower + upper) / evals * 1e-3, generic_json or os.path.join(ROOT, "profiles", "generic_latest.json"))
     eng.close()
     del states
     torch.cuda.empty_cache()
@@ -329,6 +469,11 @@ def main():
                          "it on fewer GPUs")
     ap.add_argument("--deterministic-sum", action="store_true",
                     help="N > 1 ranks: one all-gather + the pairwise sum of physher_amd/sharding.py::tree_sum instead of one all-reduce: bit for bit the one-GPU result")
+    ap.add_argument("--generic-json", default=os.path.join(ROOT, "profiles", "generic_latest.json"),
+                    help="per-evaluation MFMA / HBM counters of the cfg3 / cfg4 workloads from profiles/collect_generic.sh (used only for the same build of the library)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 under torch.distributed.run: create the RCCL process group and run the all-reduce in a world of one "
+                         "(the code path of N > 1 on a one-GPU box; the timed loop then includes the collective)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the dominant kernel from a rocprofv3 --pmc run of this workload")
     args = ap.parse_args()
@@ -352,7 +497,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if args.force_collective and "RANK" not in os.environ:
+        raise SystemExit("--force-collective needs a rendezvous: launch with torch.distributed.run --nproc-per-node 1")
+    if collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -444,12 +592,14 @@ def main():
             lnl_, cg_ = eng.gradient()
             return epilogue(np.concatenate([[lnl_], cg_.reshape(-1)]), N, cat_rates, cat_props)
     else:
+        timers = {}
         step = ShardedLikelihood(evaluate_shard, N, cat_rates, cat_props, world, result, via_host=rehearsal, tail=n_tail,
-                                 deterministic=args.deterministic_sum)  # + one RCCL all-reduce (or all-gather) + host epilogue
+                                 deterministic=args.deterministic_sum, force_collective=args.force_collective,
+                                 timers=timers)  # + one RCCL all-reduce (or all-gather) + host epilogue
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if collective:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -457,22 +607,32 @@ def main():
         lnl, bg = step()[:2]
     fence()
     prof = dict(lower_ms=0.0, upper_ms=0.0, matrices_ms=0.0, reduce_ms=0.0)
+    if not single:
+        timers.clear()
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lnl, bg = step()[:2]
+        ts = time.perf_counter()
+        lnl, bg = step()[:2]  # (ends in a device-to-host copy of the result: nothing is left in flight)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
         p = eng.profile()  # HIP-event times of this evaluation, recorded on the engine's stream
         for k in prof:
             prof[k] += p[k]
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    rank_ms = [1e3 * elapsed / args.steps]
+    if collective:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        every = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)  # every rank's own clock over the same K steps: the line reports the slowest (and the spread)
+        rank_ms = [1e3 * float(x.item()) / args.steps for x in every]
+        elapsed = max(float(x.item()) for x in every)
+    plk_timed = eng.pattern_log_likelihoods() if (world == 1 and not single and not args.no_cpu_baseline) else None  # of the last timed evaluation
     for k in prof:
         prof[k] /= max(1, args.steps)
     p = eng.profile()
 
+    failed = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps / elapsed
@@ -543,6 +703,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            # this rank's wall clock per step (host loop included): the box-to-box spread is +-5 %, the step-to-step spread is here
+            "step_ms": {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)), "mean": float(np.mean(step_ms)), "max": float(np.max(step_ms))},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -555,7 +717,16 @@ def main():
                        "parallelism": (f"{args.gpus} GPUs in one process (phyamd_create_sharded), host sum" if single else
                                        f"{world} process(es), one per GPU" + ("" if world == 1 else (", one all-gather + pairwise sum" if args.deterministic_sum else ", one RCCL all-reduce"))),
                        "taxa": T, "patterns": P, "categories": C, "states": S, "patterns_per_gpu": Pl // args.gpus if single else Pl, "lnL": lnl,
-                       "rescaling": eng.rescaling, "device_bytes": p["device_bytes"], "tiles": p["tiles"]},
+                       "rescaling": eng.rescaling, "device_bytes": p["device_bytes"], "tiles": p["tiles"],
+                       # where a step's time goes besides the kernels: the collective as the engine's stream saw it (two events around
+                       # it), the O(N C) host epilogue, and every rank's own ms per step
+                       "collective": None if single else {
+                           "backend": (dist.get_backend() if collective else None), "world": (dist.get_world_size() if collective else 1),
+                           "kind": None if not collective else ("all_gather + pairwise sum" if args.deterministic_sum else "all_reduce(SUM)"),
+                           "bytes": int(result.numel() * 8),
+                           "all_reduce_us": (float(np.mean(timers["all_reduce_us"])) if timers.get("all_reduce_us") else None),
+                           "host_epilogue_us": (float(np.mean(timers["host_epilogue_us"])) if timers.get("host_epilogue_us") else None),
+                           "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)}}},
             "roofline": {"bound": "hbm", "kernel": f"{upper_kernel} (pre-order pass + fused branch gradient)",
                          # achieved / frac: MEASURED HBM bytes of the launch (PMC, per the guide's FETCH_SIZE / WRITE_SIZE recipe)
                          # over the live HIP-event time of the same kernel; null when no PMC file matches this shape
@@ -576,11 +747,8 @@ def main():
         if traffic is not None and tj.get("lower_bytes_per_launch") and prof["lower_ms"] > 0 and p["lower_launches"] == tj.get("lower_launches_per_eval", 1):
             lb = tj["lower_bytes_per_launch"] * p["lower_launches"] / (prof["lower_ms"] * 1e-3) / 1e9
             out["roofline"]["lower_kernel"].update({"achieved": lb, "frac": lb / HBM_PEAK_GBS, "traffic": tj["lower_bytes_per_launch"]})
-        if S != 4:  # the 20-/61-state contraction runs on the fp64 matrix cores: report that side of the roofline too
-            fl = algorithmic_flops(T, Pl, C, S)
-            tf = fl / ((prof["lower_ms"] + prof["upper_ms"]) * 1e-3) / 1e12 if prof["upper_ms"] > 0 else None
-            out["roofline"]["mfma"] = {"achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": None if tf is None else tf / FP64_MFMA_PEAK_TFLOPS, "algorithmic_flops_per_eval": fl}
+        if S != 4 and prof["upper_ms"] > 0:  # the 20-/61-state contraction runs on the fp64 matrix cores: report that side of the roofline too
+            out["roofline"]["mfma"] = mfma_object(args.config, T, Pl, C, S, (prof["lower_ms"] + prof["upper_ms"]) * 1e-3, args.generic_json)
             if S > 20:
                 out["roofline"]["bound"] = "mfma"
         if p["tiles"] > 1:  # the engine's per-kernel timings describe the last tile only: no roofline claim for a tiled run
@@ -592,7 +760,12 @@ def main():
             out["cpu_baseline"] = {"value": 1.0 / scaled, "unit": "evals/s", "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
                                    "sample_seconds_per_eval": cb["t_eval"], "sample_patterns": cb["patterns"]}
             if cb.get("shards"):
-                out["cpu_baseline"]["shards"] = cb["shards"]
+                out["cpu_baseline"]["shards"] = [{k: v for k, v in sh.items() if k != "details"} for sh in cb["shards"]]
+                if all(sh.get("details") for sh in cb["shards"]) and p["tiles"] == 1 and not args.subst_gradient:
+                    gc = check_against_reference(eng, tree, states, weights, cb["shards"], cat_rates, cat_props, plk_timed)
+                    out["cpu_baseline"]["gradient_check"] = gc
+                    if not gc["ok"]:
+                        failed = "the timed engine disagrees with the reference (cpu_baseline.gradient_check)"
             if cb.get("lnl") is not None:
                 # the same sample (the first sites of the workload, every site with weight 1) through the engine: the reference's lnL of
                 # the driver's own run is the yardstick (relative difference; the parity tests hold 1e-10)
@@ -633,7 +806,7 @@ def main():
             out["other_configs"] = []
             for cfg in ("cfg2", "cfg3", "cfg4"):
                 try:
-                    out["other_configs"].append(time_other_config(cfg, device, stream, args.seed, 10))
+                    out["other_configs"].append(time_other_config(cfg, device, stream, args.seed, 10, args.generic_json))
                 except Exception as exc:  # a secondary measurement must not lose the headline line
                     out["other_configs"].append({"workload": cfg, "error": str(exc)})
         if world == 1 and not single and not args.no_drop_in and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1 and not args.subst_gradient:
@@ -653,8 +826,11 @@ def main():
                 out["drop_in"] = di
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
+    if failed:
+        print(f"[bench] FAILED: {failed}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

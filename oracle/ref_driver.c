@@ -737,6 +737,43 @@ int main(int argc, char **argv) {
 		double t3 = now_ms();
 		printf("{\"lnl\":%.17g,\"iters\":%d,\"lnl_ms_per_eval\":%.6f,\"grad_ms_per_eval\":%.6f,\"patterns\":%d,\"taxa\":%d,\"rescaled\":%s}\n", lnl, iters,
 		       (t1 - t0) / iters, (t3 - t2) / iters, tlk->sp->count, Tree_tip_count(tlk->tree), tlk->scale ? "true" : "false");
+		if (argc > 5) {
+			/* what the timed protocol computed, for the caller to hold its own numbers against: the gradient vector of one more
+			 * TreeLikelihood_gradient call (TREE_MODEL flag, entry = node id), the per-pattern lnL, and the compressed patterns
+			 * (one string per taxon, character '0' + state code) with their weights */
+			Tree *tree = tlk->tree;
+			SitePattern *pat = tlk->sp;
+			const int N = Tree_node_count(tree);
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			tlk->m->need_update = true;
+			double *g = TreeLikelihood_gradient(b.mlike);
+			FILE *o = fopen(argv[5], "w");
+			if (!o) { fprintf(stderr, "cannot write %s\n", argv[5]); return 2; }
+			fprintf(o, "{\n");
+			jarr(o, "gradient", g, N, true);
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			tlk->m->need_update = true;
+			lnl = b.mlike->logP(b.mlike);
+			fprintf(o, "\"lnl\":%.17g,\n", lnl);
+			jarr(o, "pattern_lk", tlk->pattern_lk, pat->count, true);
+			jarr(o, "weights", pat->weights, pat->count, true);
+			fprintf(o, "\"taxa\":[");
+			for (int i = 0; i < pat->size; i++) fprintf(o, "%s\"%s\"", i ? "," : "", pat->names[i]);
+			fprintf(o, "],\n\"patterns\":[");
+			for (int i = 0; i < pat->size; i++) {
+				fprintf(o, "%s\"", i ? "," : "");
+				for (int k = 0; k < pat->count; k++) fputc('0' + (int)pat->patterns[i][k], o);
+				fprintf(o, "\"");
+			}
+			fprintf(o, "],\n\"nodes\":[");
+			for (int i = 0; i < N; i++) {
+				Node *n = Tree_node(tree, i);
+				fprintf(o, "%s{\"id\":%d,\"name\":\"%s\",\"left\":%d,\"right\":%d,\"distance\":%.17g}", i ? "," : "", n->id, n->name ? n->name : "",
+				        n->left ? n->left->id : -1, n->right ? n->right->id : -1, Node_distance(n));
+			}
+			fprintf(o, "],\n\"root\":%d\n}\n", Tree_root(tree)->id);
+			fclose(o);
+		}
 		return 0;
 	}
 	fprintf(stderr, "unknown mode %s\n", argv[1]);

@@ -59,15 +59,16 @@ def tree_sum(parts):
     return total
 
 
-def all_reduce_result(result, world: int, via_host: bool = False, deterministic: bool = False):
+def all_reduce_result(result, world: int, via_host: bool = False, deterministic: bool = False, force: bool = False):
     """In-place SUM of the per-shard [lnL, cat-gradient] vector (a torch tensor on the engine's device).
+    force: run the collective even in a world of one (a process group must exist): the RCCL path of a one-GPU rehearsal.
 
     Default: ONE all-reduce (RCCL over xGMI on GPUs) -- the order of the additions is the collective's.
     deterministic: ONE all-gather of the same 64 KB vectors and the pairwise tree_sum on every rank -- with shard_range's
     ranges the result is bit for bit that of one GPU.
     via_host: rehearsal mode for a one-GPU box (several ranks share the card, gloo group): the 64 KB vector makes a
     round trip through host memory because gloo cannot reduce device tensors on ROCm."""
-    if world > 1:
+    if world > 1 or force:
         import torch
         import torch.distributed as dist
         src = result.cpu() if (via_host and result.is_cuda) else result
@@ -101,10 +102,15 @@ class ShardedLikelihood:
     kernels.  (Handle 0, torch's default stream, means "engine-owned stream" to phyamd_create and is NOT ordered with torch.)
     """
 
-    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False, tail=0, deterministic=False):
+    def __init__(self, evaluate_shard, node_count, cat_rates, cat_props, world, result_buffer, via_host=False, tail=0, deterministic=False,
+                 force_collective=False, timers=None):
         """tail > 0: the vector carries `tail` more per-shard sums after the cat-gradient (Engine.parameter_gradient_device:
-        substitution-parameter sums, then the root frequency term); they ride in the same all-reduce and are returned third."""
+        substitution-parameter sums, then the root frequency term); they ride in the same all-reduce and are returned third.
+        timers: a dict that receives, per call, "all_reduce_us" (device time of the collective between two events on the current
+        stream -- the engine's) and "host_epilogue_us"."""
         self.tail = tail
+        self.force = force_collective
+        self.timers = timers
         self.via_host = via_host
         self.deterministic = deterministic
         self.evaluate_shard = evaluate_shard
@@ -115,10 +121,24 @@ class ShardedLikelihood:
         self.result = result_buffer
 
     def __call__(self):
+        import time
         self.evaluate_shard(self.result)
-        all_reduce_result(self.result, self.world, self.via_host, self.deterministic)
+        timed = self.timers is not None and (self.world > 1 or self.force) and self.result.is_cuda and not self.via_host
+        if timed:
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        all_reduce_result(self.result, self.world, self.via_host, self.deterministic, self.force)
+        if timed:
+            e1.record()
         host = self.result.detach().cpu().numpy()
+        t0 = time.perf_counter()
         lnl, grad = epilogue(host, self.N, self.cat_rates, self.cat_props)
+        if self.timers is not None:
+            self.timers.setdefault("host_epilogue_us", []).append(1e6 * (time.perf_counter() - t0))
+            if timed:
+                e1.synchronize()
+                self.timers.setdefault("all_reduce_us", []).append(1e3 * e0.elapsed_time(e1))
         if self.tail:
             return lnl, grad, host[1 + self.N * len(self.cat_rates):][:self.tail].copy()
         return lnl, grad

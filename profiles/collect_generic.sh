@@ -30,5 +30,7 @@ for cfg in cfg3 cfg4; do
 	done
 done
 cd "$ROOT"
-for cfg in cfg3 cfg4; do python3 bench.py --no-cpu-baseline --config $cfg --steps 10 --warmup 2 > "$OUT/${TAG}_${cfg}_bench.json" 2>> "$OUT/$cfg.err"; done
+# counter figures per evaluation, tied to this binary: copy to profiles/generic_latest.json for bench.py's other_configs[].mfma
+python3 profiles/generic_counters.py "$TAG" "$OUT" > "$OUT/${TAG}_generic_counters.json"
+for cfg in cfg3 cfg4; do python3 bench.py --generic-json "$OUT/${TAG}_generic_counters.json" --no-cpu-baseline --config $cfg --steps 10 --warmup 2 > "$OUT/${TAG}_${cfg}_bench.json" 2>> "$OUT/$cfg.err"; done
 ls "$OUT" >&2

@@ -66,3 +66,44 @@ def test_bench_two_rank_launch_path():
     lo, hi = shard_range(3000, 0, 2)  # whole 64-pattern blocks by bisection: rank 0 holds a subtree of the one-GPU summation
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["patterns_per_gpu"] == hi - lo == 1472
     assert d["config"]["lnL"] == one["config"]["lnL"]  # ... so the sum of the two ranks is bit for bit the one-rank result
+
+
+def test_bench_line_carries_step_statistics_and_collective_fields():
+    d = _run(["--no-cpu-baseline"])
+    s = d["step_ms"]
+    assert s["min"] <= s["median"] <= s["max"] and s["min"] > 0
+    c = d["config"]["collective"]
+    assert c["world"] == 1 and c["backend"] is None and c["all_reduce_us"] is None and c["host_epilogue_us"] > 0
+    assert c["rank_ms_per_step"]["min"] == c["rank_ms_per_step"]["max"] > 0
+
+
+def test_bench_cpu_baseline_checks_the_timed_engine_against_the_reference():
+    """cpu_baseline.gradient_check: per-pattern lnL and the branch gradient of the TIMED engine against the reference's own values
+    for the baseline's shards (present when oracle/_ref is built; a miss makes bench.py exit non-zero, which _run asserts against)"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_driver")):
+        pytest.skip("oracle/_ref is not built (needs the reference tree)")
+    d = _run([])
+    gc = d["cpu_baseline"]["gradient_check"]
+    assert gc["ok"] and len(gc["shards"]) >= 1
+    for sh in gc["shards"]:
+        assert sh["ok"] and sh["per_pattern_lnl_max_rel_err"] <= 1e-11 and sh["lnl_rel_err"] <= 1e-10
+        assert sh["gradient_max_abs_err"] <= 1e-9 * max(1.0, sh["gradient_inf_norm"]) and sh["branches_compared"] == 2 * 24 - 3
+
+
+def test_bench_rccl_path_in_a_world_of_one():
+    """The N > 1 code path with the REAL backend on one GPU: launched as the driver launches N ranks (torch.distributed.run, here
+    --nproc-per-node 1), --force-collective creates the RCCL ("nccl") process group and runs the all-reduce of the result vector
+    on the engine's stream in a world of one.  (A child process: nothing here re-executes a process that has touched the GPU.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--taxa", "24", "--patterns", "3000",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    c = d["config"]["collective"]
+    assert c["backend"] == "nccl" and c["world"] == 1 and c["kind"] == "all_reduce(SUM)" and c["bytes"] == 8 * (1 + 47 * 4)
+    assert c["all_reduce_us"] is not None and c["all_reduce_us"] > 0 and c["host_epilogue_us"] > 0
+    one = _run(["--no-cpu-baseline"])
+    assert d["config"]["lnL"] == one["config"]["lnL"] and d["n_gpus"] == 1  # the collective of one rank changes nothing

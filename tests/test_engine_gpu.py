@@ -1247,3 +1247,49 @@ def test_root_terms_agree_between_rescaled_and_unscaled_evaluations():
         assert b.rescaling and abs(la - lb) <= 1e-11 * abs(la)
         assert abs(a.root_invariant_term() - b.root_invariant_term()) <= 1e-10 * max(1.0, abs(a.root_invariant_term()))
         np.testing.assert_allclose(a.root_frequency_term(), b.root_frequency_term(), rtol=1e-10)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_driver")),
+                    reason="oracle/_ref is not built (needs the reference tree)")
+def test_headline_taxa_gradient_vector_against_the_reference_itself(tmp_path):
+    """1000 taxa x 8000 sites of the bench's generator: the compiled reference (ref_driver bench ... details: the protocol of
+    examples/benchmarking.c:485-503) yields its gradient vector, per-pattern lnL and compressed patterns; the engine holds the
+    sites uncompressed, as the bench does, and is compared node by node through the clade map (bench.py::check_against_reference,
+    the routine behind cpu_baseline.gradient_check)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from physher_amd import synth
+    T, L = 1000, 8000
+    rng = np.random.default_rng(77)
+    tree = synth.random_tree(T, rng)
+    states = np.ascontiguousarray(synth.evolve(tree, L, 4, rng))
+    rates, props = bench.category_rates(4)
+    ev, U, Ui = bench.gtr_eigen()
+    (tmp_path / "aln.fa").write_text(synth.to_fasta(tree.names, states, "nucleotide"))
+    (tmp_path / "tree.nwk").write_text(tree.newick() + "\n")
+    (tmp_path / "spec.txt").write_text(f"fasta {tmp_path}/aln.fa\nnewick {tmp_path}/tree.nwk\ndatatype nucleotide\nmodel gtr\n"
+                                       f"rates {','.join(map(str, bench.GTR_RATES[:5]))}\nfreqs {','.join(map(str, bench.GTR_FREQS))}\n"
+                                       f"categories 4\nalpha {bench.ALPHA}\ntipstates 0\nsse 1\n")
+    driver = os.path.join(root, "oracle", "_ref", "ref_driver")
+    subprocess.run([driver, "bench", str(tmp_path / "spec.txt"), "1", "0", str(tmp_path / "details.json")], check=True, capture_output=True, timeout=600)
+    details = json.loads((tmp_path / "details.json").read_text())
+    weights = np.ones(L)
+    with Engine(T, L, 4, 4) as e:
+        e.set_topology(tree.left, tree.right, tree.root)
+        e.set_branch_lengths(tree.length)
+        e.set_eigen(ev, U, Ui)
+        e.set_frequencies(np.array(bench.GTR_FREQS))
+        e.set_category_rates(rates, props)
+        e.set_pattern_weights(weights)
+        for t in range(T):
+            e.set_tip_states(t, states[t])
+        e.gradient()
+        plk = e.pattern_log_likelihoods()
+        gc = bench.check_against_reference(e, tree, states, weights, [dict(first_site=0, details=details)], rates, props, plk)
+    assert gc["ok"], gc
+    sh = gc["shards"][0]
+    assert sh["branches_compared"] == 2 * T - 3 and sh["sites"] == L and sh["reference_patterns"] <= L
