@@ -396,12 +396,15 @@ def time_other_config(config, device, stream, seed, evals, generic_json=None):
     return out
 
 
-def drop_in_measure(config, device, seed, iters):
+def drop_in_measure(config, device, seed, iters, tipstates=1):
     """What a user of the REFERENCE gets from the binding (INTEGRATION.md seam A): physher's own object graph, built by its own JSON
     parser from a FASTA file and a Newick string, with integration/physher_device.c in front of libphyc -- timed by the protocol of
     examples/benchmarking.c:498-503 (oracle/_ref/ref_driver bench: invalidate every node and the eigen system, then
-    TreeLikelihood_gradient with the TREE_MODEL flag), in a process of its own.  Test infrastructure built where the reference
-    tree exists (oracle/_ref travels to the GPU box prebuilt); None where it is absent."""
+    TreeLikelihood_gradient with the TREE_MODEL flag), in a process of its own.  tipstates = 0 is the wrapper's default tip mode
+    (src/phycpp/physher.hpp:366-367: use_tip_states = false, 0/1 partials per tip).  Also reported: the process's peak resident
+    host memory (wait4's ru_maxrss) and its wall time, which is mostly construction (FASTA parsing, pattern compression, the
+    object graph, tips to the device).  Test infrastructure built where the reference tree exists (oracle/_ref travels to the GPU
+    box prebuilt); None where it is absent."""
     from physher_amd import synth
     refdir = os.path.join(ROOT, "oracle", "_ref")
     driver, shim = os.path.join(refdir, "ref_driver"), os.path.join(refdir, "libphysher_device.so")
@@ -412,31 +415,47 @@ def drop_in_measure(config, device, seed, iters):
     if S != 4:
         return None
     tree = synth.random_tree(T, np.random.default_rng(seed))
-    states = np.ascontiguousarray(evolve_on_device(tree, P, seed * 100003, device, S).cpu().numpy())
+    BLK = 125000
     with tempfile.TemporaryDirectory() as d:
-        with open(os.path.join(d, "aln.fa"), "w") as f:
-            f.write(synth.to_fasta(tree.names, states, "nucleotide"))
+        rows = [[] for _ in range(T)]
+        for b0 in range(0, P, BLK):  # block-wise: the same sites as the main workload (which generates them in blocks of 125000)
+            st = evolve_on_device(tree, min(BLK, P - b0), seed * 100003 + (b0 if config == "cfg5" else 0), device, S).cpu().numpy()
+            table = np.frombuffer(b"ACGT", dtype="S1")
+            for t in range(T):
+                rows[t].append(table[st[t]].tobytes())
+            del st
+        with open(os.path.join(d, "aln.fa"), "wb") as f:
+            for t in range(T):
+                f.write(b">" + tree.names[t].encode() + b"\n" + b"".join(rows[t]) + b"\n")
+        del rows
         with open(os.path.join(d, "tree.nwk"), "w") as f:
             f.write(tree.newick() + "\n")
         with open(os.path.join(d, "spec.txt"), "w") as f:
             f.write(f"fasta {d}/aln.fa\nnewick {d}/tree.nwk\ndatatype nucleotide\nmodel gtr\n"
                     f"rates {','.join(map(str, GTR_RATES[:5]))}\nfreqs {','.join(map(str, GTR_FREQS))}\n"
-                    f"categories {C}\nalpha {ALPHA}\ntipstates 1\nsse 1\n")
+                    f"categories {C}\nalpha {ALPHA}\ntipstates {tipstates}\nsse 1\n")
         env = dict(os.environ)
         env["LD_PRELOAD"] = shim
         env["PHYSHER_DEVICE"] = "1"
         env["PHYSHER_DEVICE_VERBOSE"] = "1"
         t0 = time.perf_counter()
-        out = subprocess.run([driver, "bench", os.path.join(d, "spec.txt"), str(iters), "2"], capture_output=True, text=True, env=env, timeout=900)
+        with open(os.path.join(d, "out.txt"), "w") as fo, open(os.path.join(d, "err.txt"), "w") as fe:
+            proc = subprocess.Popen([driver, "bench", os.path.join(d, "spec.txt"), str(iters), "2"], stdout=fo, stderr=fe, env=env)
+            _, status, ru = os.wait4(proc.pid, 0)
+            proc.returncode = os.waitstatus_to_exitcode(status)
         wall = time.perf_counter() - t0
-    if out.returncode != 0:
-        return {"error": (out.stderr or out.stdout)[-400:]}
-    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        out_text, err_text = open(os.path.join(d, "out.txt")).read(), open(os.path.join(d, "err.txt")).read()
+    if proc.returncode != 0:
+        return {"error": (err_text or out_text)[-400:], "tipstates": tipstates}
+    r = json.loads([ln for ln in out_text.splitlines() if ln.startswith("{")][-1])
+    timed_s = iters * (r["grad_ms_per_eval"] + r["lnl_ms_per_eval"]) / 1e3
     return {"workload": f"{wl['name']}, {T} taxa x {P} sites -> {r['patterns']} patterns x {S} states x {C} categories (BASELINE configs[{int(config[3]) - 1}]), "
                         f"physher's own JSON model + SingleTreeLikelihood + TreeLikelihood_gradient (TREE_MODEL) with the device binding preloaded",
+            "tipstates": tipstates,
             "evals_per_s": 1e3 / r["grad_ms_per_eval"], "ms_per_eval": r["grad_ms_per_eval"], "lnl_only_ms_per_eval": r["lnl_ms_per_eval"], "lnL": r["lnl"],
-            "patterns": r["patterns"], "iters": iters, "process_wall_s": wall,
-            "device_work": (out.stderr.strip().splitlines() or [""])[-1][-160:]}
+            "patterns": r["patterns"], "iters": iters, "process_wall_s": wall, "construction_s": max(0.0, wall - timed_s),
+            "host_rss_gb": ru.ru_maxrss * 1024.0 / 1e9,
+            "device_work": (err_text.strip().splitlines() or [""])[-1][-160:]}
 
 
 def main():
@@ -811,7 +830,11 @@ def main():
                     out["other_configs"].append({"workload": cfg, "error": str(exc)})
         if world == 1 and not single and not args.no_drop_in and args.config == "cfg5" and args.taxa is None and args.patterns is None and p["tiles"] == 1 and not args.subst_gradient:
             try:
-                di = drop_in_measure(args.drop_in_config, device, args.seed, 20 if args.drop_in_config == "cfg2" else 5)
+                di = drop_in_measure(args.drop_in_config, device, args.seed, 20 if args.drop_in_config == "cfg2" else 5, 1)
+                if di is not None and "evals_per_s" in di:  # ... and in the wrapper's default tip mode (0/1 partials per tip)
+                    d0 = drop_in_measure(args.drop_in_config, device, args.seed, 20 if args.drop_in_config == "cfg2" else 5, 0)
+                    di["tip_partials_mode"] = {k: d0.get(k) for k in ("tipstates", "evals_per_s", "ms_per_eval", "lnL", "process_wall_s", "construction_s",
+                                                                       "host_rss_gb", "error") if k in d0}
             except Exception as exc:
                 di = {"error": str(exc)}
             if di is not None:

@@ -96,6 +96,12 @@ typedef struct binding {
 
 static binding *g_bindings = NULL;
 
+/* objects built without host partial arrays (see "host storage of an object that is going to the device" below) */
+static bool is_lean(const SingleTreeLikelihood *tlk);
+static void lean_to_full(SingleTreeLikelihood *tlk);
+static void lean_unshare(SingleTreeLikelihood *tlk);
+static void forget_lean(const SingleTreeLikelihood *tlk);
+
 /* PHYSHER_DEVICE_VERBOSE=1: a line at exit saying how much work went to the device (the tests read it: a run that silently
  * stayed on the CPU kernels would print zeros) */
 static unsigned long g_likelihood_calls = 0, g_gradient_calls = 0, g_branch_calls = 0;
@@ -768,7 +774,10 @@ static void release_binding(SingleTreeLikelihood *tlk, bool alive) {
 	double *owned[] = {b->mats, b->bl, b->rates, b->props, b->freqs, b->eigen, b->st_bl, b->st_rates, b->st_props, b->st_freqs, b->st_eigen, b->pgrad, b->rootf, b->scratch};
 	for (size_t i = 0; i < sizeof owned / sizeof owned[0]; i++) free(owned[i]);
 	free(b);
-	if (alive) SingleTreeLikelihood_update_all_nodes(tlk);
+	if (alive) {
+		if (is_lean(tlk)) lean_to_full(tlk);
+		SingleTreeLikelihood_update_all_nodes(tlk);
+	}
 }
 
 void SingleTreeLikelihood_disable_device(SingleTreeLikelihood *tlk) { release_binding(tlk, true); }
@@ -779,6 +788,10 @@ void free_SingleTreeLikelihood_internals(SingleTreeLikelihood *tlk) {
 	static void (*real)(SingleTreeLikelihood *);
 	if (!real) real = next_symbol("free_SingleTreeLikelihood_internals");
 	release_binding(tlk, false);
+	if (is_lean(tlk)) {
+		lean_unshare(tlk);
+		forget_lean(tlk);
+	}
 	real(tlk);
 }
 
@@ -786,6 +799,157 @@ void free_SingleTreeLikelihood_internals(SingleTreeLikelihood *tlk) {
 /* switches: JSON key "device" and the environment variable PHYSHER_DEVICE                                        */
 
 static int g_json_decision = -1; /* >= 0 while new_TreeLikelihoodModel_from_json is building an object: the JSON key wins */
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* host storage of an object that is going to the device                                                          */
+/* new_SingleTreeLikelihood gives every node a [C][P][S] array, twice (lower and upper partials), and fills and      */
+/* category-replicates one per tip when "tipstates" is off (treelikelihood.c:947-1005, 1047, 1106-1117): 256 GB of  */
+/* address space and 128 GB of touched pages at 1000 taxa x 1e6 patterns x 4 categories, none of which a             */
+/* device-enabled object reads.  allocate_storage is an exported function (treelikelihood.c:68), so the object is    */
+/* built LEAN when the device has already been asked for (JSON key seen, or PHYSHER_DEVICE set; PHYSHER_DEVICE_LEAN=0 */
+/* opts out): no arrays for internal nodes and uppers, ONE scratch array shared by all tips (the constructor's       */
+/* get_partials writes land there; SingleTreeLikelihood_enable_device sends each tip to the engine from the site     */
+/* pattern itself).  Disabling the device on a live object gives it the reference's full storage back.               */
+
+typedef struct lean_rec {
+	SingleTreeLikelihood *tlk;
+	struct lean_rec *next;
+} lean_rec;
+static lean_rec *g_lean = NULL;
+
+static bool is_lean(const SingleTreeLikelihood *tlk) {
+	for (lean_rec *r = g_lean; r; r = r->next)
+		if (r->tlk == tlk) return true;
+	return false;
+}
+
+static void forget_lean(const SingleTreeLikelihood *tlk) {
+	for (lean_rec **pp = &g_lean; *pp; pp = &(*pp)->next)
+		if ((*pp)->tlk == tlk) {
+			lean_rec *r = *pp;
+			*pp = r->next;
+			free(r);
+			return;
+		}
+}
+
+static bool device_wanted_now(void) {
+	const char *lean = getenv("PHYSHER_DEVICE_LEAN");
+	if (lean && atoi(lean) == 0) return false;
+	if (g_json_decision >= 0) return g_json_decision > 0;
+	const char *env = getenv("PHYSHER_DEVICE");
+	return env && atoi(env) > 0;
+}
+
+/* one table of a lean object: every tip that holds partials points at `shared`, everything else is NULL */
+static double **lean_table(SingleTreeLikelihood *tlk, double *shared) {
+	double **rows = calloc(tlk->partials_dim, sizeof(double *));
+	if (!tlk->use_tip_states)
+		for (int i = 0; i < Tree_node_count(tlk->tree); i++) {
+			Node *n = Tree_node(tlk->tree, i);
+			if (Node_isleaf(n)) rows[Node_id(n)] = shared;
+		}
+	return rows;
+}
+
+static double *lean_scratch(const SingleTreeLikelihood *tlk) {
+	void *p = NULL;
+	if (tlk->use_tip_states) return NULL;
+	if (posix_memalign(&p, 16, sizeof(double) * (size_t)tlk->partials_size) != 0) {
+		fprintf(stderr, "physher device backend: out of host memory for the tip scratch array\n");
+		exit(2);
+	}
+	return p;
+}
+
+static double **small_matrices(const SingleTreeLikelihood *tlk) {
+	double **m = malloc(sizeof(double *) * tlk->matrix_dim);
+	for (int i = 0; i < tlk->matrix_dim; i++) {
+		void *p = NULL;
+		if (posix_memalign(&p, 16, sizeof(double) * (size_t)tlk->matrix_size * tlk->sm->cat_count) != 0) exit(2);
+		m[i] = p;
+	}
+	return m;
+}
+
+void allocate_storage(SingleTreeLikelihood *tlk, size_t index) {
+	static void (*real)(SingleTreeLikelihood *, size_t);
+	if (!real) real = next_symbol("allocate_storage");
+	if (index == 0 ? !device_wanted_now() : !is_lean(tlk)) {
+		real(tlk, index);
+		return;
+	}
+	const size_t nodes = Tree_node_count(tlk->tree);
+	if (index == 0) {
+		lean_rec *r = malloc(sizeof(lean_rec));
+		r->tlk = tlk;
+		r->next = g_lean;
+		g_lean = r;
+		tlk->current_matrices_indexes = calloc(2 * nodes, sizeof(unsigned));
+		tlk->current_partials_indexes = calloc(2 * nodes, sizeof(unsigned));
+		tlk->stored_matrices_indexes = NULL;
+		tlk->stored_partials_indexes = NULL;
+		tlk->partials = malloc(2 * sizeof(double **));
+		tlk->partials[0] = lean_table(tlk, lean_scratch(tlk));
+		tlk->partials[1] = NULL;
+		tlk->matrices = malloc(2 * sizeof(double **));
+		tlk->matrices[0] = small_matrices(tlk);
+		tlk->matrices[1] = NULL;
+	} else { /* first store (treelikelihood.c:125-137) */
+		tlk->stored_matrices_indexes = calloc(2 * nodes, sizeof(unsigned));
+		tlk->stored_partials_indexes = calloc(2 * nodes, sizeof(unsigned));
+		tlk->partials[1] = lean_table(tlk, lean_scratch(tlk));
+		tlk->matrices[1] = small_matrices(tlk);
+	}
+}
+
+/* the destructor frees every non-NULL row: leave the shared array in one of them */
+static void lean_unshare(SingleTreeLikelihood *tlk) {
+	for (int t = 0; t < 2; t++) {
+		double **rows = tlk->partials[t];
+		if (!rows) continue;
+		double *shared = NULL;
+		for (int i = 0; i < tlk->partials_dim; i++) {
+			if (!rows[i]) continue;
+			if (!shared) shared = rows[i];
+			else if (rows[i] == shared) rows[i] = NULL;
+		}
+	}
+}
+
+/* a lean object goes back to the CPU kernels: the reference's own storage, tips refilled as its constructor fills them */
+static void lean_to_full(SingleTreeLikelihood *tlk) {
+	static void (*real)(SingleTreeLikelihood *, size_t);
+	if (!real) real = next_symbol("allocate_storage");
+	const bool had_store = tlk->partials[1] != NULL;
+	lean_unshare(tlk);
+	for (int t = 0; t < 2; t++) {
+		if (!tlk->partials[t]) continue;
+		for (int i = 0; i < tlk->partials_dim; i++) free(tlk->partials[t][i]);
+		free(tlk->partials[t]);
+		for (int i = 0; i < tlk->matrix_dim; i++) free(tlk->matrices[t][i]);
+		free(tlk->matrices[t]);
+	}
+	free(tlk->partials);
+	free(tlk->matrices);
+	free(tlk->current_matrices_indexes);
+	free(tlk->current_partials_indexes);
+	free(tlk->stored_matrices_indexes);
+	free(tlk->stored_partials_indexes);
+	forget_lean(tlk);
+	real(tlk, 0);
+	if (had_store) real(tlk, 1);
+	if (!tlk->use_tip_states)
+		for (int t = 0; t < (had_store ? 2 : 1); t++)
+			for (int i = 0; i < Tree_node_count(tlk->tree); i++) {
+				Node *n = Tree_node(tlk->tree, i);
+				if (!Node_isleaf(n)) continue;
+				double *row = tlk->partials[t][Node_id(n)];
+				tlk->sp->get_partials(tlk->sp, tlk->mapping[Node_id(n)], row);
+				for (size_t k = 1; k < (size_t)tlk->cat_count; k++)
+					memcpy(row + k * tlk->m->nstate * tlk->pattern_count, row, sizeof(double) * tlk->m->nstate * tlk->pattern_count);
+			}
+}
 
 static void enable_n(SingleTreeLikelihood *tlk, Model *model, int n) {
 	if (n <= 0) return;

@@ -776,6 +776,36 @@ int main(int argc, char **argv) {
 		}
 		return 0;
 	}
+	if (!strcmp(argv[1], "toggle")) {
+		/* device -> CPU on a live object: lnL and the TREE_MODEL gradient with the binding enabled (as the environment asks), then
+		 * SingleTreeLikelihood_disable_device and the same two on the reference's own kernels -- an object built without host
+		 * partial arrays (integration/physher_device.c, "lean") has to get the reference's storage back.  Prints both. */
+		spec_t sp;
+		read_spec(argv[2], &sp);
+		built_t b = build_from_spec(&sp);
+		SingleTreeLikelihood *tlk = b.mlike->obj;
+		const int N = Tree_node_count(tlk->tree);
+		FILE *o = fopen(argv[3], "w");
+		fprintf(o, "{\n\"on_device_before\":%d,\n", on_device(tlk));
+		for (int pass = 0; pass < 2; pass++) {
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			double lnl = b.mlike->logP(b.mlike);
+			TreeLikelihood_initialize_gradient(b.mlike, TREELIKELIHOOD_FLAG_TREE_MODEL);
+			SingleTreeLikelihood_update_all_nodes(tlk);
+			double *g = TreeLikelihood_gradient(b.mlike);
+			fprintf(o, "\"lnl%d\":%.17g,\n", pass, lnl);
+			char key[32];
+			snprintf(key, sizeof key, "gradient%d", pass);
+			jarr(o, key, g, N, true);
+			if (pass == 0) {
+				void (*off)(SingleTreeLikelihood *) = (void (*)(SingleTreeLikelihood *))dlsym(RTLD_DEFAULT, "SingleTreeLikelihood_disable_device");
+				if (off) off(tlk);
+			}
+		}
+		fprintf(o, "\"on_device_after\":%d\n}\n", on_device(tlk));
+		fclose(o);
+		return 0;
+	}
 	fprintf(stderr, "unknown mode %s\n", argv[1]);
 	return 2;
 }

@@ -236,3 +236,49 @@ def test_two_shards_through_the_binding(case, tmp_path):
     np.testing.assert_allclose(np.array(dev["pattern_lk"]), gold["pattern_lk"], rtol=1e-10, atol=1e-10)
     close_where_finite(dev["gradient_tree"], gold["gradient_tree"], 1e-9, "gradient_tree")
     close_where_finite(dev["gradient_all"], gold["gradient_all"], 1e-8, "gradient_all")
+
+
+def _synthetic_spec(tmp_path, T, L, tipstates, seed=5):
+    from physher_amd import synth
+    rng = np.random.default_rng(seed)
+    tree = synth.random_tree(T, rng)
+    states = np.ascontiguousarray(synth.evolve(tree, L, 4, rng))
+    (tmp_path / "aln.fa").write_text(synth.to_fasta(tree.names, states, "nucleotide"))
+    (tmp_path / "tree.nwk").write_text(tree.newick() + "\n")
+    (tmp_path / "spec.txt").write_text(f"fasta {tmp_path}/aln.fa\nnewick {tmp_path}/tree.nwk\ndatatype nucleotide\nmodel gtr\nrates 1.2,3.1,0.7,0.9,2.8\n"
+                                       f"freqs 0.3,0.2,0.2,0.3\ncategories 4\nalpha 0.5\ntipstates {tipstates}\nsse 1\n")
+    return str(tmp_path / "spec.txt")
+
+
+def test_device_objects_are_built_without_host_partial_arrays(tmp_path):
+    """The wrapper's default tip mode ("tipstates" off): the reference's constructor fills one [C][P][S] array per tip
+    (treelikelihood.c:1106-1117: 128 GB at the headline shape).  With the device asked for, the binding's allocate_storage hands
+    every tip ONE shared scratch array and internal nodes none: the process's peak resident memory stays far below the full
+    arrays' size (PHYSHER_DEVICE_LEAN=0 = the reference's own storage, same numbers)."""
+    T, L = 120, 60000  # tips alone: 120 x 60000 x 16 doubles = 0.92 GB
+    spec = _synthetic_spec(tmp_path, T, L, 0)
+    res = {}
+    for lean in ("1", "0"):
+        proc = subprocess.Popen([DRIVER, "bench", spec, "2", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                env=device_env(PHYSHER_DEVICE=1, PHYSHER_DEVICE_LEAN=lean))
+        _, status, ru = os.wait4(proc.pid, 0)
+        out, err = proc.stdout.read(), proc.stderr.read()
+        assert os.waitstatus_to_exitcode(status) == 0, err[-2000:]
+        r = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+        res[lean] = (r["lnl"], ru.ru_maxrss * 1024 / 1e9)
+        lik, grad, _ = device_work(err)
+        assert lik >= 2 and grad >= 2
+    assert res["1"][0] == res["0"][0]
+    assert res["0"][1] > 0.9, res  # the reference's own storage: every tip array touched
+    assert res["1"][1] < res["0"][1] - 0.7, res
+
+
+@pytest.mark.parametrize("tipstates", [0, 1])
+def test_disabling_the_device_on_a_live_lean_object_restores_the_cpu_path(tmp_path, tipstates):
+    spec = _synthetic_spec(tmp_path, 30, 400, tipstates, seed=8)
+    out = run([DRIVER, "toggle", spec, str(tmp_path / "t.json")], str(tmp_path), device_env(PHYSHER_DEVICE=1))
+    d = json.loads((tmp_path / "t.json").read_text())
+    assert d["on_device_before"] == 1 and d["on_device_after"] == 0
+    assert abs(d["lnl0"] - d["lnl1"]) <= 1e-10 * abs(d["lnl1"])
+    g0, g1 = np.array(d["gradient0"]), np.array(d["gradient1"])
+    assert np.abs(g0 - g1).max() <= 1e-9 * max(1.0, np.abs(g1).max())
