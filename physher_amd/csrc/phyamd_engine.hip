@@ -1,7 +1,7 @@
 // phyamd_engine.hip -- MI355X (gfx950) tree-likelihood engine behind include/physher_amd.h.
 //
 // One translation unit, assembled from:
-//   phyamd_device.inc / _level4 / _walk4 / _walk4s / _general / _patterns   device code (kernels)
+//   phyamd_device.inc / _level4 / _walk4 / _walk4s / _general / _genwalk / _patterns   device code (kernels)
 //   phyamd_shard.inc        state of one engine on one GPU (= one shard of the site patterns)
 //   phyamd_schedule.inc     level and tree-walk schedules, device storage
 //   phyamd_launch.inc       kernel launches per pass
@@ -9,19 +9,24 @@
 //   phyamd_shard_api.inc    per-device half of the C ABI
 //   phyamd_abi.inc          extern "C" entry points: a handle is a group of 1..n shards on 1..n GPUs
 //
-// Replaces the CPU hot path of physher's SingleTreeLikelihood (src/phyc/treelikelihood.c and the
-// per-state-count kernel files) with hand-written HIP kernels.  Design:
-//   * one thread owns one site pattern and loops over the rate categories, so per-pattern work
-//     (rescaling max, mixture denominators, weights) never leaves the thread;
-//   * transition matrices P(t) and dP/dt are built on the device from the cached eigen system and
-//     reach the kernels through wave-uniform (scalar) loads;
-//   * the tree is executed level by level: one launch covers every node of a level
-//     (blockIdx.y = node, blockIdx.x = pattern block), so launch count = tree height, not node count;
-//   * the pre-order pass computes BOTH children's upper partials from one read of the parent's upper
-//     and fuses the branch-length gradient (dP/dt contraction, state sum, 1/L_k, weights, pattern
-//     reduction) into the same kernel: the reference's spare_partials array never exists;
-//   * reductions are fixed-order (wave shuffle -> LDS -> per-block slab -> reduction kernel), so
-//     results are bitwise reproducible run to run.
+// Replaces the CPU hot path of physher's SingleTreeLikelihood (src/phyc/treelikelihood.c and the per-state-count kernel files)
+// with hand-written HIP kernels.  The shipped design:
+//   * 4 states: a wave keeps 64 site patterns of one rate category (one per lane) and WALKS THE TREE -- the post-order pass and
+//     the pre-order pass + branch gradient are each one depth-first walk over a host-built op list (two launches: cut subtrees,
+//     then the top of the tree), values handed from op to op in registers, short-lived ones parked in LDS.  Cherries, cherry +
+//     tip nodes and nodes above them with 4-6 tips below are never stored: they are rebuilt from 4-bit tip codes wherever needed.
+//     Both walks are software pipelines: packed mask words, per-op table blocks (LDS-DMA) and stored operands of op i + 1 are
+//     requested while op i computes (phyamd_walk4s.inc; phyamd_walk4.inc = the table-gather form for parameter gradients and
+//     rescaled evaluations with more than four categories; phyamd_level4.inc = one launch per tree level for incremental updates,
+//     keep_partials and the reference-compatible rescaled gradients);
+//   * 20 / 60 / 61 states: P . partial on v_mfma_f64_16x16x4 from LDS matrix images, one launch per tree level (pre-order) or a
+//     depth-first walk (20-state post-order), cherries fused (phyamd_general.inc, phyamd_genwalk.inc);
+//   * transition matrices are built on the device from the cached eigen system and reach the 4-state kernels through
+//     wave-uniform (scalar) loads;
+//   * the pre-order pass computes BOTH children's uppers from one read of the parent's upper and fuses the branch-length
+//     gradient into the same kernel: the reference's spare_partials array never exists;
+//   * reductions are fixed-order (matrix-pipe cross-lane sums, per-block slabs, bisection-ordered segment sums), so results are
+//     bitwise reproducible run to run and independent of how many GPUs share the patterns.
 //
 // gfx950 only; no CUDA/compat paths.
 
@@ -113,7 +118,6 @@ struct NodeOp {
 #include "phyamd_device.inc"
 #include "phyamd_level4.inc"
 #include "phyamd_walk4.inc"
-#include "phyamd_walk4mx.inc"
 #include "phyamd_walk4s.inc"
 #include "phyamd_general.inc"
 #include "phyamd_genwalk.inc"

@@ -871,20 +871,6 @@ def test_tiny_trees_and_ragged_pattern_counts(S):
                             assert abs(lt - o["lnl"]) <= 1e-10 * abs(o["lnl"]), (T, P, C, resc)
 
 
-@pytest.mark.parametrize("T,P,C,fold", [(60, 333, 4, False), (33, 67, 1, False), (70, 130, 4, True), (9, 3, 2, False)])
-def test_matrix_core_walk_matches_oracle(monkeypatch, T, P, C, fold):
-    """PHYAMD_WALK_MX=1: the plain pre-order walk with its 4 x 4 mat-vecs on v_mfma_f64_4x4x4 (phyamd_walk4mx.inc; off by
-    default: measured slower than the vector-ALU walk).  Same schedule, op list, park slots and slabs; results to rounding.
-    Pattern counts that are not multiples of 4 / 64 exercise the dword mask reads at the end of a tip's row."""
-    monkeypatch.setenv("PHYAMD_WALK_MX", "1")
-    pb = random_problem(T, P, C, seed=5 * T + P, S=4, gaps=0.05, fold_root_freqs=1 if fold else 0)
-    o = pb.gradient()
-    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
-        lnl, cg = e.gradient(GRAD_FOLD_ROOT_FREQS if fold else 0)
-        assert abs(lnl - o["lnl"]) <= 1e-10 * abs(o["lnl"])
-        np.testing.assert_allclose(cg, o["cat_grad"], rtol=1e-9, atol=1e-9 * np.abs(o["cat_grad"]).max())
-
-
 def _caterpillar(T):
     N = 2 * T - 1
     left, right = np.full(N, -1, np.int32), np.full(N, -1, np.int32)
