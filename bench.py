@@ -454,7 +454,7 @@ def drop_in_measure(config, device, seed, iters, tipstates=1):
             "tipstates": tipstates,
             "evals_per_s": 1e3 / r["grad_ms_per_eval"], "ms_per_eval": r["grad_ms_per_eval"], "lnl_only_ms_per_eval": r["lnl_ms_per_eval"], "lnL": r["lnl"],
             "patterns": r["patterns"], "iters": iters, "process_wall_s": wall, "construction_s": max(0.0, wall - timed_s),
-            "host_rss_gb": ru.ru_maxrss * 1024.0 / 1e9,
+            "host_rss_gb": r["peak_rss_kb"] * 1024.0 / 1e9,  # VmHWM of the driver process itself (wait4's ru_maxrss includes what this process held at fork)
             "device_work": (err_text.strip().splitlines() or [""])[-1][-160:]}
 
 

@@ -520,6 +520,19 @@ static void dump_gradients_unrooted(FILE *o, Model *mlike) {
 	}
 }
 
+/* peak resident memory of THIS process image in kB (VmHWM of /proc/self/status: unlike wait4's ru_maxrss it does not
+ * include what the parent held when it forked) */
+static long peak_rss_kb(void) {
+	FILE *f = fopen("/proc/self/status", "r");
+	if (!f) return -1;
+	char line[256];
+	long kb = -1;
+	while (fgets(line, sizeof line, f))
+		if (!strncmp(line, "VmHWM:", 6)) kb = atol(line + 6);
+	fclose(f);
+	return kb;
+}
+
 static double now_ms(void) {
 	struct timespec t;
 	clock_gettime(CLOCK_MONOTONIC_RAW, &t);
@@ -735,8 +748,8 @@ int main(int argc, char **argv) {
 			TreeLikelihood_gradient(b.mlike);
 		}
 		double t3 = now_ms();
-		printf("{\"lnl\":%.17g,\"iters\":%d,\"lnl_ms_per_eval\":%.6f,\"grad_ms_per_eval\":%.6f,\"patterns\":%d,\"taxa\":%d,\"rescaled\":%s}\n", lnl, iters,
-		       (t1 - t0) / iters, (t3 - t2) / iters, tlk->sp->count, Tree_tip_count(tlk->tree), tlk->scale ? "true" : "false");
+		printf("{\"lnl\":%.17g,\"iters\":%d,\"lnl_ms_per_eval\":%.6f,\"grad_ms_per_eval\":%.6f,\"patterns\":%d,\"taxa\":%d,\"rescaled\":%s,\"peak_rss_kb\":%ld}\n", lnl,
+		       iters, (t1 - t0) / iters, (t3 - t2) / iters, tlk->sp->count, Tree_tip_count(tlk->tree), tlk->scale ? "true" : "false", peak_rss_kb());
 		if (argc > 5) {
 			/* what the timed protocol computed, for the caller to hold its own numbers against: the gradient vector of one more
 			 * TreeLikelihood_gradient call (TREE_MODEL flag, entry = node id), the per-pattern lnL, and the compressed patterns

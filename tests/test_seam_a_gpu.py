@@ -259,14 +259,10 @@ def test_device_objects_are_built_without_host_partial_arrays(tmp_path):
     spec = _synthetic_spec(tmp_path, T, L, 0)
     res = {}
     for lean in ("1", "0"):
-        proc = subprocess.Popen([DRIVER, "bench", spec, "2", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                env=device_env(PHYSHER_DEVICE=1, PHYSHER_DEVICE_LEAN=lean))
-        _, status, ru = os.wait4(proc.pid, 0)
-        out, err = proc.stdout.read(), proc.stderr.read()
-        assert os.waitstatus_to_exitcode(status) == 0, err[-2000:]
-        r = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
-        res[lean] = (r["lnl"], ru.ru_maxrss * 1024 / 1e9)
-        lik, grad, _ = device_work(err)
+        out = run([DRIVER, "bench", spec, "2", "1"], str(tmp_path), device_env(PHYSHER_DEVICE=1, PHYSHER_DEVICE_LEAN=lean))
+        r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        res[lean] = (r["lnl"], r["peak_rss_kb"] * 1024 / 1e9)  # VmHWM of the driver process itself
+        lik, grad, _ = device_work(out.stderr)
         assert lik >= 2 and grad >= 2
     assert res["1"][0] == res["0"][0]
     assert res["0"][1] > 0.9, res  # the reference's own storage: every tip array touched
