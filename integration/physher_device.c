@@ -139,8 +139,25 @@ static void die_on(int rc, const char *what) {
 	exit(2);
 }
 
+/* Two ways into the reference (see the header comment and integration/physher-device.patch):
+ *   interposition (default): this library defines the reference's own symbols and sits in front of libphyc; "the reference's
+ *     function" is the next definition in the lookup order;
+ *   PHYSHER_DEVICE_PATCHED: the reference carries the hook table of physher-device.patch; the same functions are compiled under
+ *     private names (pd_...) and installed in that table when the library is loaded; "the reference's function" is the function
+ *     itself, which runs its own body when called back from its hook.  Nothing depends on symbol lookup order then: static
+ *     libphyc, -Bsymbolic, -fno-semantic-interposition and LTO builds all work. */
+#ifdef PHYSHER_DEVICE_PATCHED
+#define HOOK(name) pd_##name
+#else
+#define HOOK(name) name
+#endif
+
 static void *next_symbol(const char *name) {
+#ifdef PHYSHER_DEVICE_PATCHED
+	void *p = dlsym(RTLD_DEFAULT, name);
+#else
 	void *p = dlsym(RTLD_NEXT, name);
+#endif
 	if (!p) {
 		fprintf(stderr, "physher device backend: the reference's %s is not behind this library (link order / LD_PRELOAD)\n", name);
 		exit(2);
@@ -474,7 +491,7 @@ static void device_parameter_gradient(binding *b, double *cat_gradient) {
  * on the device), and at 1e5 patterns the loop costs as much as the device's whole gradient.  The loop's bound is
  * tlk->sp->count, read per iteration: it is 0 for the duration of the call.  A maintainer writes `if (!tlk->device)` around
  * the loop instead.  (Nothing else the function reaches on a device-enabled object reads the pattern count.) */
-void TreeLikelihood_calculate_gradient(Model *model, double *grads) {
+void HOOK(TreeLikelihood_calculate_gradient)(Model *model, double *grads) {
 	static void (*real)(Model *, double *);
 	if (!real) real = next_symbol("TreeLikelihood_calculate_gradient");
 	SingleTreeLikelihood *tlk = (SingleTreeLikelihood *)model->obj;
@@ -491,7 +508,7 @@ void TreeLikelihood_calculate_gradient(Model *model, double *grads) {
 /* SingleTreeLikelihood_update_uppers (treelikelihood.c:1530-1538: what serial_brent_optimize_tree calls first, optimizer.c:125)
  * runs the static CPU pass _calculate_simple and the CPU pre-order pass; on a device object it means "evaluate, then serve
  * single-branch trials": the engine rebuilds the one upper a trial needs on demand */
-void SingleTreeLikelihood_update_uppers(SingleTreeLikelihood *tlk) {
+void HOOK(SingleTreeLikelihood_update_uppers)(SingleTreeLikelihood *tlk) {
 	static void (*real)(SingleTreeLikelihood *);
 	if (!find_binding(tlk)) {
 		if (!real) real = next_symbol("SingleTreeLikelihood_update_uppers");
@@ -504,14 +521,14 @@ void SingleTreeLikelihood_update_uppers(SingleTreeLikelihood *tlk) {
 	tlk->use_upper = true;
 }
 
-void update_upper_partials(SingleTreeLikelihood *tlk, Node *node, bool include_root_freqs) {
+void HOOK(update_upper_partials)(SingleTreeLikelihood *tlk, Node *node, bool include_root_freqs) {
 	static void (*real)(SingleTreeLikelihood *, Node *, bool);
 	if (find_binding(tlk)) return; /* the pre-order pass is fused with the gradient (gradient_cat_branch_lengths below) */
 	if (!real) real = next_symbol("update_upper_partials");
 	real(tlk, node, include_root_freqs);
 }
 
-void gradient_cat_branch_lengths(SingleTreeLikelihood *tlk, double *branch_gradient, const double *pattern_likelihoods) {
+void HOOK(gradient_cat_branch_lengths)(SingleTreeLikelihood *tlk, double *branch_gradient, const double *pattern_likelihoods) {
 	static void (*real)(SingleTreeLikelihood *, double *, const double *);
 	binding *b = find_binding(tlk);
 	if (!b) {
@@ -528,7 +545,7 @@ void gradient_cat_branch_lengths(SingleTreeLikelihood *tlk, double *branch_gradi
 	g_gradient_calls++;
 }
 
-double calculate_dlnl_dQ(SingleTreeLikelihood *tlk, int index, const double *pattern_likelihoods) {
+double HOOK(calculate_dlnl_dQ)(SingleTreeLikelihood *tlk, int index, const double *pattern_likelihoods) {
 	static double (*real)(SingleTreeLikelihood *, int, const double *);
 	binding *b = find_binding(tlk);
 	if (!b) {
@@ -541,7 +558,7 @@ double calculate_dlnl_dQ(SingleTreeLikelihood *tlk, int index, const double *pat
 
 /* the +I term reads the root partial (treelikelihood.c:2943-3008): one O(P) reduction on the device, the rest is the
  * reference's O(N C) arithmetic on the per-category branch gradient */
-void gradient_pinv_sitemodel(SingleTreeLikelihood *tlk, const double *branch_gradient, const double *branch_lengths, double *gradient) {
+void HOOK(gradient_pinv_sitemodel)(SingleTreeLikelihood *tlk, const double *branch_gradient, const double *branch_lengths, double *gradient) {
 	static void (*real)(SingleTreeLikelihood *, const double *, const double *, double *);
 	binding *b = find_binding(tlk);
 	if (!b) {
@@ -555,7 +572,7 @@ void gradient_pinv_sitemodel(SingleTreeLikelihood *tlk, const double *branch_gra
 	gradient[0] = tlk->sm->derivative(tlk->sm, discrete_grad, Parameters_at(tlk->sm->proportions->parameters, 0));
 }
 
-void gradient_pinv_W_sitemodel(SingleTreeLikelihood *tlk, const double *branch_gradient, const double *branch_lengths, double *gradient) {
+void HOOK(gradient_pinv_W_sitemodel)(SingleTreeLikelihood *tlk, const double *branch_gradient, const double *branch_lengths, double *gradient) {
 	static void (*real)(SingleTreeLikelihood *, const double *, const double *, double *);
 	binding *b = find_binding(tlk);
 	if (!b) {
@@ -784,7 +801,7 @@ void SingleTreeLikelihood_disable_device(SingleTreeLikelihood *tlk) { release_bi
 
 /* _treeLikelihood_model_free (treelikelihood.c:694-713) frees the tree, the models and the site pattern BEFORE it calls this:
  * nothing of tlk's object graph may be touched here */
-void free_SingleTreeLikelihood_internals(SingleTreeLikelihood *tlk) {
+void HOOK(free_SingleTreeLikelihood_internals)(SingleTreeLikelihood *tlk) {
 	static void (*real)(SingleTreeLikelihood *);
 	if (!real) real = next_symbol("free_SingleTreeLikelihood_internals");
 	release_binding(tlk, false);
@@ -872,7 +889,7 @@ static double **small_matrices(const SingleTreeLikelihood *tlk) {
 	return m;
 }
 
-void allocate_storage(SingleTreeLikelihood *tlk, size_t index) {
+void HOOK(allocate_storage)(SingleTreeLikelihood *tlk, size_t index) {
 	static void (*real)(SingleTreeLikelihood *, size_t);
 	if (!real) real = next_symbol("allocate_storage");
 	if (index == 0 ? !device_wanted_now() : !is_lean(tlk)) {
@@ -972,7 +989,7 @@ static void enable_n(SingleTreeLikelihood *tlk, Model *model, int n) {
 	}
 }
 
-Model *new_TreeLikelihoodModel(const char *name, SingleTreeLikelihood *tlk, Model *tree, Model *m, Model *sm, Model *bm) {
+Model *HOOK(new_TreeLikelihoodModel)(const char *name, SingleTreeLikelihood *tlk, Model *tree, Model *m, Model *sm, Model *bm) {
 	static Model *(*real)(const char *, SingleTreeLikelihood *, Model *, Model *, Model *, Model *);
 	if (!real) real = next_symbol("new_TreeLikelihoodModel");
 	Model *model = real(name, tlk, tree, m, sm, bm);
@@ -981,7 +998,7 @@ Model *new_TreeLikelihoodModel(const char *name, SingleTreeLikelihood *tlk, Mode
 	return model;
 }
 
-Model *new_TreeLikelihoodModel_from_json(json_node *node, Hashtable *hash) {
+Model *HOOK(new_TreeLikelihoodModel_from_json)(json_node *node, Hashtable *hash) {
 	static Model *(*real)(json_node *, Hashtable *);
 	if (!real) real = next_symbol("new_TreeLikelihoodModel_from_json");
 	/* "device": true | false | <number of GPUs>; taken out of the node while the reference checks its allowed keys (:820-832) */
@@ -1009,3 +1026,12 @@ Model *new_TreeLikelihoodModel_from_json(json_node *node, Hashtable *hash) {
 	}
 	return model;
 }
+
+#ifdef PHYSHER_DEVICE_PATCHED
+/* the table of physher-device.patch, installed when this library is loaded */
+static const TreeLikelihoodDeviceHooks g_hooks = {
+    pd_new_TreeLikelihoodModel, pd_new_TreeLikelihoodModel_from_json, pd_allocate_storage, pd_free_SingleTreeLikelihood_internals,
+    pd_SingleTreeLikelihood_update_uppers, pd_update_upper_partials, pd_calculate_dlnl_dQ, pd_gradient_cat_branch_lengths,
+    pd_gradient_pinv_sitemodel, pd_gradient_pinv_W_sitemodel, pd_TreeLikelihood_calculate_gradient};
+__attribute__((constructor)) static void install_hooks(void) { treelikelihood_device_hooks = &g_hooks; }
+#endif

@@ -278,3 +278,17 @@ def test_disabling_the_device_on_a_live_lean_object_restores_the_cpu_path(tmp_pa
     assert abs(d["lnl0"] - d["lnl1"]) <= 1e-10 * abs(d["lnl1"])
     g0, g1 = np.array(d["gradient0"]), np.array(d["gradient1"])
     assert np.abs(g0 - g1).max() <= 1e-9 * max(1.0, np.abs(g1).max())
+
+
+def test_patched_reference_runs_on_the_device_without_interposition():
+    """integration/physher-device.patch: the reference as a STATIC library with the hook table, the binding built with
+    -DPHYSHER_DEVICE_PATCHED -- no LD_PRELOAD, no interposable symbol -- and the reference's own known-answer test on the engine."""
+    exe = os.path.join(REFDIR, "test_tree_likelihood_patched")
+    if not os.path.exists(exe):
+        pytest.skip("test_tree_likelihood_patched is not built")
+    env = dict(os.environ, PHYSHER_DEVICE="1", PHYSHER_DEVICE_VERBOSE="1")
+    env.pop("LD_PRELOAD", None)
+    out = run([exe], os.path.join(GOLDEN, "fluA_jc69_time"), env)
+    assert "ALL TESTS" in out.stdout and "PASSED" in out.stdout and "FAILED" not in out.stdout, out.stdout[-2000:]
+    lik, grad, _ = device_work(out.stderr)
+    assert lik >= 2 and grad >= 2, (lik, grad)
