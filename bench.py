@@ -709,7 +709,7 @@ def main():
             upper_kernel = "k_upper4_stream" if kern == "4_walk" and C <= 4 and p["tiles"] == 1 and not os.environ.get("PHYAMD_WALK_STREAM") == "0" else f"k_upper{kern}"
         lower_kernel = ((tj.get("kernels") or {}).get("lower") or {}).get("kernel") if traffic is not None else None
         if not lower_kernel:  # (the streamed post-order walk runs plain 4-state evaluations with <= 4 categories)
-            lower_kernel = ("k_lower4_stream" if kern == "4_walk" and C <= 4 and not eng.rescaling and os.environ.get("PHYAMD_LOWER_STREAM") != "0" else
+            lower_kernel = ("k_lower4_stream" if kern == "4_walk" and (C <= 4 or os.environ.get("PHYAMD_SCALE_EXP2") != "0") and os.environ.get("PHYAMD_LOWER_STREAM") != "0" else
                             (f"k_lower{kern}" if p["lower_launches"] <= 2 or S != 4 else "k_lower4"))
         workload_label = f"{T}-taxon {wl['name'].split(' (')[0]} fp64, {P:.0e} site patterns".replace("e+0", "e").replace("e+", "e")
         out = {

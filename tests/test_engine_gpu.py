@@ -1279,3 +1279,58 @@ def test_headline_taxa_gradient_vector_against_the_reference_itself(tmp_path):
     assert gc["ok"], gc
     sh = gc["shards"][0]
     assert sh["branches_compared"] == 2 * T - 3 and sh["sites"] == L and sh["reference_patterns"] <= L
+
+
+@pytest.mark.parametrize("T,P,C,shape", [(400, 700, 4, "random"), (900, 130, 3, "caterpillar"), (256, 257, 1, "balanced"), (300, 200, 6, "random")])
+def test_power_of_two_rescaling_of_the_streamed_walks(monkeypatch, T, P, C, shape):
+    """Rescaled evaluations of the streamed walks scale every category by its own powers of two (integer exponents, no exchange
+    between the category waves: phyamd_walk4s.inc, exp2_rescale) unless a caller needs stored partials in the reference's
+    convention.  lnL, per-pattern lnL and the gradient against the oracle; the same numbers (to rounding) with
+    PHYAMD_SCALE_EXP2=0; then the callers that force the reference's convention -- a single-branch evaluation, a changed branch
+    (incremental update), stored partials read back -- each still equal to the oracle, and the gradient after the switch too."""
+    pb = random_problem(T, P, C, seed=31 * T + P, shape=shape, gaps=0.03, bl=(0.3, 0.9), rescale=1)
+    ref = pb.gradient(want_partials=True)
+    assert ref["rescaled"]
+    tol = 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+    with engine_from_problem(pb, rescale=RESCALE_ALWAYS) as e:
+        lnl, cg = e.gradient()
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"]) and np.abs(cg - ref["cat_grad"]).max() <= tol
+        np.testing.assert_allclose(e.pattern_log_likelihoods(), ref["pattern_lk"], rtol=1e-11, atol=1e-11)
+        assert e.log_likelihood() == lnl  # the post-order walk alone: the same bits
+        lnl2, cg2 = e.gradient()
+        assert lnl2 == lnl and np.array_equal(cg, cg2)  # reproducible
+        # a single-branch evaluation needs the reference's convention: the post-order pass runs again, the numbers stay
+        node = T + 3
+        lt, d1, _ = e.branch_log_likelihood(node, pb.branch_lengths[node])
+        assert abs(lt - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
+        lnl3, cg3 = e.gradient()
+        assert abs(lnl3 - ref["lnl"]) <= 1e-10 * abs(ref["lnl"]) and np.abs(cg3 - ref["cat_grad"]).max() <= tol
+    monkeypatch.setenv("PHYAMD_SCALE_EXP2", "0")
+    with engine_from_problem(pb, rescale=RESCALE_ALWAYS) as e:
+        lnl0, cg0 = e.gradient()
+        assert abs(lnl0 - lnl) <= 1e-12 * abs(lnl) and np.abs(cg0 - cg).max() <= tol
+    monkeypatch.delenv("PHYAMD_SCALE_EXP2")
+    with engine_from_problem(pb, rescale=RESCALE_ALWAYS) as e:
+        e.gradient()
+        # a changed branch after a power-of-two pass: the incremental update cannot read those partials, everything is recomputed
+        bl = pb.branch_lengths.copy()
+        bl[5] *= 1.7
+        e.set_branch_length(5, bl[5])
+        q = po.Problem(pb.left, pb.right, pb.root, pb.weights, pb.eval, pb.evec, pb.ivec, pb.freqs, pb.cat_rates, pb.cat_props, bl, tip_states=pb.tip_states, rescale=1)
+        r2 = q.gradient()
+        lnl4, cg4 = e.gradient()
+        assert abs(lnl4 - r2["lnl"]) <= 1e-10 * abs(r2["lnl"]) and np.abs(cg4 - r2["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(r2["cat_grad"]).max())
+    with engine_from_problem(pb, rescale=RESCALE_ALWAYS) as e:
+        e.gradient()
+        # stored partials read back are the reference's (its scale factors), whatever the walks used in between
+        stored = [n for n in range(T, pb.N) if _is_stored(e, n)]
+        for n in stored[:5] + [pb.root]:
+            np.testing.assert_allclose(e.partials(n), ref["lower"][n], rtol=1e-9, atol=1e-300)
+
+
+def _is_stored(e, node):
+    try:
+        e.partials(node)
+        return True
+    except EngineError:
+        return False
