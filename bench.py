@@ -753,6 +753,10 @@ def main():
                          "frac": None if achieved is None else achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "pmc_profile": pmc_source, "pmc_note": pmc_note, "kernel_resources": tj.get("kernels") if traffic is not None else None,
                          "valu": valu,
+                         # SURVEY 8(d)'s algorithmic flops of the WHOLE evaluation over the step time, against the fp64 vector peak
+                         # (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz): the kernels recompute fringe / DEEP nodes, so they issue more
+                         "fp64_vector": {"achieved": algorithmic_flops(T, Pl, C, S) / (ms_per_step * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": algorithmic_flops(T, Pl, C, S) / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
                          # the reference's three-pass algorithmic bytes over the same time: the fused kernels move about
                          # a tenth of them, so this ratio exceeds 1 and is NOT a fraction of any roof
                          "vs_three_pass": None if three_pass is None else
