@@ -987,6 +987,44 @@ def test_fused_cherries_at_20_states(monkeypatch):
     np.testing.assert_allclose(results["1"][1], results["0"][1], rtol=1e-11, atol=1e-11 * np.abs(results["0"][1]).max())
 
 
+def test_tip_rate_products_follow_the_model_at_20_states():
+    """20 states: the branch term of a tip child is a column of the image of Qf P(t) (k_tip_rate_products; Qf = diag(pi) Q, or Q
+    when pi is folded into the uppers), built once per state of the model.  One engine asked for both conventions in turn, then
+    with other branch lengths, other frequencies (a new eigen system with them) and other category rates must follow every time:
+    a stale image shows in the gradient of the tip branches only (lnL does not use it)."""
+    from golden_util import reversible_eigen
+    pb = random_problem(26, 210, 2, seed=911, S=20, gaps=0.04)
+    tips = np.arange(pb.T)
+
+    def check(e, fold):
+        pb.fold_root_freqs = 1 if fold else 0
+        o = pb.gradient()
+        lnl, cg = e.gradient(GRAD_FOLD_ROOT_FREQS if fold else 0)
+        assert abs(lnl - o["lnl"]) <= 1e-10 * abs(o["lnl"])
+        scale = np.abs(o["cat_grad"]).max()
+        np.testing.assert_allclose(cg, o["cat_grad"], rtol=1e-9, atol=1e-9 * scale)
+        assert np.abs(o["cat_grad"][tips]).max() > 1e-3 * scale  # the tip branches carry weight in this check
+
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        check(e, False)
+        check(e, True)   # Qf changes from diag(pi) Q to Q
+        check(e, False)  # and back
+        pb.branch_lengths[:] = pb.branch_lengths * np.random.default_rng(5).uniform(0.5, 2.0, size=pb.N)
+        e.set_branch_lengths(pb.branch_lengths)
+        check(e, False)
+        rng = np.random.default_rng(6)
+        pb.freqs = rng.dirichlet(np.full(20, 4.0))
+        r = rng.uniform(0.5, 3.0, size=(20, 20))
+        pb.eval, pb.evec, pb.ivec = (np.ascontiguousarray(a, dtype=np.float64) for a in reversible_eigen(0.5 * (r + r.T), pb.freqs))
+        e.set_eigen(pb.eval, pb.evec, pb.ivec)
+        e.set_frequencies(pb.freqs)
+        check(e, True)
+        check(e, False)
+        pb.cat_rates = np.array([0.3, 1.7])
+        e.set_category_rates(pb.cat_rates, pb.cat_props)
+        check(e, False)
+
+
 @pytest.mark.parametrize("case", ["gtr_g4_t16", "gtr_g4_t24_gaps_tipstates", "wag_g4_t12", "mg94_t8"])
 @pytest.mark.parametrize("resident", [False, True])
 def test_single_branch_evaluation_matches_reference_fixture(case, resident):
