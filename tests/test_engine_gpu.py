@@ -119,7 +119,12 @@ def _compare_with_oracle(pb, rescale, flags=0, tip_mode="states", check_partials
             e.set_keep_partials(True)
         lnl_only = e.log_likelihood()
         lnl, cg = e.gradient(flags)
-        assert lnl == lnl_only  # fixed-order reductions: bitwise reproducible
+        if (flags & GRAD_COMPAT_SCALED) and e.rescaling:
+            # the reference's per-category arithmetic reads stored partials in the reference's own rescaling convention: the post-order
+            # pass has run again (the streamed walks keep powers of two per category between them), other factors, the same lnL to rounding
+            assert abs(lnl - lnl_only) <= 1e-13 * abs(lnl)
+        else:
+            assert lnl == lnl_only  # fixed-order reductions: bitwise reproducible
         assert e.rescaling == ref["rescaled"]
         assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"])
         np.testing.assert_allclose(e.pattern_log_likelihoods(), ref["pattern_lk"], rtol=1e-11, atol=1e-11)
@@ -1364,6 +1369,74 @@ def test_power_of_two_rescaling_of_the_streamed_walks(monkeypatch, T, P, C, shap
         stored = [n for n in range(T, pb.N) if _is_stored(e, n)]
         for n in stored[:5] + [pb.root]:
             np.testing.assert_allclose(e.partials(n), ref["lower"][n], rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("T,P,C,shape", [(400, 700, 4, "random"), (900, 130, 3, "caterpillar"), (256, 257, 1, "balanced")])
+def test_carried_storage_of_the_streamed_walks(monkeypatch, T, P, C, shape):
+    """Between the two streamed 4-state walks a stored node is t_n = P_n p_n (k_lower4_stream TF: the pre-order walk takes a stored
+    child as its message).  lnL, per-pattern lnL and both gradient conventions against the oracle; the same numbers to rounding with
+    PHYAMD_STREAM_TFORM=0; then every caller that reads stored partials -- partials read back, a single-branch evaluation, a changed
+    branch (incremental update), the substitution-parameter gradient, store / restore -- gets the partials themselves (the post-order
+    pass runs again once) and still equals the oracle, as does the gradient afterwards."""
+    pb = random_problem(T, P, C, seed=17 * T + P, shape=shape, gaps=0.03)
+    ref = pb.gradient(want_partials=True)
+    tol = 1e-9 * max(1.0, np.abs(ref["cat_grad"]).max())
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        lnl, cg = e.gradient()
+        assert abs(lnl - ref["lnl"]) <= 1e-10 * abs(ref["lnl"]) and np.abs(cg - ref["cat_grad"]).max() <= tol
+        np.testing.assert_allclose(e.pattern_log_likelihoods(), ref["pattern_lk"], rtol=1e-11, atol=1e-11)
+        assert e.log_likelihood() == lnl
+        pb.fold_root_freqs = 1
+        rf = pb.gradient()
+        pb.fold_root_freqs = 0
+        lnl_f, cg_f = e.gradient(GRAD_FOLD_ROOT_FREQS)  # stays on the streamed walks (no post-order pass in between)
+        assert lnl_f == lnl and np.abs(cg_f - rf["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(rf["cat_grad"]).max())
+        # stored partials read back are the partials themselves
+        stored = [n for n in range(T, pb.N) if _is_stored(e, n)]
+        assert len(stored) >= 3
+        for n in stored[:4] + [pb.root]:
+            np.testing.assert_allclose(e.partials(n), ref["lower"][n], rtol=1e-9, atol=1e-300)
+        lnl2, cg2 = e.gradient()
+        assert abs(lnl2 - lnl) <= 1e-13 * abs(lnl) and np.abs(cg2 - ref["cat_grad"]).max() <= tol
+    monkeypatch.setenv("PHYAMD_STREAM_TFORM", "0")
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        lnl0, cg0 = e.gradient()
+        assert abs(lnl0 - lnl) <= 1e-13 * abs(lnl) and np.abs(cg0 - cg).max() <= 1e-11 * max(1.0, np.abs(cg).max())
+    monkeypatch.delenv("PHYAMD_STREAM_TFORM")
+    ref_bg = po.branch_gradient_from_cat(ref["cat_grad"], pb.cat_rates, pb.cat_props)
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        e.gradient()
+        node = stored[1]
+        lt, d1, _ = e.branch_log_likelihood(node, pb.branch_lengths[node])  # a stored node's own branch: needs p_node
+        assert abs(lt - ref["lnl"]) <= 1e-10 * abs(ref["lnl"]) and abs(d1 - ref_bg[node]) <= 1e-9 * max(1.0, np.abs(ref_bg).max())
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        e.gradient()
+        bl = pb.branch_lengths.copy()
+        bl[stored[2]] *= 1.6  # an incremental update reads stored children
+        e.set_branch_length(stored[2], bl[stored[2]])
+        q = po.Problem(pb.left, pb.right, pb.root, pb.weights, pb.eval, pb.evec, pb.ivec, pb.freqs, pb.cat_rates, pb.cat_props, bl, tip_states=pb.tip_states)
+        r2 = q.gradient()
+        lnl4, cg4 = e.gradient()
+        assert abs(lnl4 - r2["lnl"]) <= 1e-10 * abs(r2["lnl"]) and np.abs(cg4 - r2["cat_grad"]).max() <= 1e-9 * max(1.0, np.abs(r2["cat_grad"]).max())
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as e:
+        lnl5, _ = e.gradient()
+        e.store()  # the stored state is kept in the compatible form
+        e.set_branch_length(stored[0], 2.0 * pb.branch_lengths[stored[0]])
+        assert e.log_likelihood() != lnl5
+        e.restore()
+        lnl6, cg6 = e.gradient()
+        assert abs(lnl6 - ref["lnl"]) <= 1e-10 * abs(ref["lnl"]) and np.abs(cg6 - ref["cat_grad"]).max() <= tol
+    # the substitution-parameter sums after a plain gradient: their kernels read stored partials
+    rng = np.random.default_rng(3)
+    dQ = rng.normal(size=(2, 4, 4))
+    dQ -= dQ.sum(axis=2, keepdims=True) * np.eye(4)[None]
+    with engine_from_problem(pb, rescale=RESCALE_NEVER) as a, engine_from_problem(pb, rescale=RESCALE_NEVER) as b:
+        a.gradient()  # a: the streamed walks first, then the parameter gradient; b: the parameter gradient at once
+        a.set_rate_matrix_derivatives(dQ)
+        b.set_rate_matrix_derivatives(dQ)
+        ra, rb = a.parameter_gradient(), b.parameter_gradient()
+        for x, y in zip(ra, rb):
+            np.testing.assert_allclose(np.asarray(x), np.asarray(y), rtol=1e-10, atol=1e-10 * max(1.0, float(np.abs(np.asarray(y)).max())))
 
 
 def _is_stored(e, node):

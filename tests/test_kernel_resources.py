@@ -23,8 +23,10 @@ def kernels():
     return table["kernels"]
 
 
-@pytest.mark.parametrize("name,max_vgpr", [("k_upper4_stream<false, 0, false>", 128), ("k_upper4_stream<true, 0, false>", 128),
-                                           ("k_lower4_stream<false, 0>", 96), ("k_lower4_stream<false, 2>", 96), ("k_lower4_walk<4, 1, false, true>", 72),
+@pytest.mark.parametrize("name,max_vgpr", [("k_upper4_stream<false, 0, false, true>", 128), ("k_upper4_stream<true, 0, false, true>", 128),
+                                           ("k_upper4_stream<false, 0, false, false>", 128),
+                                           ("k_lower4_stream<false, 0, true>", 96), ("k_lower4_stream<false, 0, false>", 96), ("k_lower4_stream<false, 2, true>", 96),
+                                           ("k_lower4_walk<4, 1, false, true>", 72),
                                            ("k_lower_gen_walk<2, 5>", 128)])
 def test_hot_kernels_keep_their_occupancy(kernels, name, max_vgpr):
     k = kernels[name]
@@ -36,8 +38,9 @@ def test_every_streamed_variant_is_in_the_library_and_spills_nothing(kernels):
     """the pre-order walk's prefetches are loads written out in assembly whose results must not be moved before the op's explicit
     wait: a spilled register set would be saved before the load has written it (phyamd_walk4s.inc, prefetch4)"""
     for fold in ("false", "true"):
-        for scale in ("0", "1", "2"):  # plain, the reference's rescaling, powers of two per category
+        # plain (stored children as partials / carried through their branches), the reference's rescaling, powers of two per category
+        for scale, tf in (("0", "false"), ("0", "true"), ("1", "false"), ("2", "true")):
             for ambig in ("false", "true"):
-                k = kernels[f"k_upper4_stream<{fold}, {scale}, {ambig}>"]
+                k = kernels[f"k_upper4_stream<{fold}, {scale}, {ambig}, {tf}>"]
                 assert k["vgpr_spill_count"] == 0 and k["scratch_bytes"] == 0, k
                 assert k["vgpr_count"] <= (128 if scale == "0" and ambig == "false" else 168), k
