@@ -21,6 +21,9 @@
 //     keep_partials and the reference-compatible rescaled gradients);
 //   * 20 / 60 / 61 states: P . partial on v_mfma_f64_16x16x4 from LDS matrix images, one launch per tree level (pre-order) or a
 //     depth-first walk (20-state post-order), cherries fused (phyamd_general.inc, phyamd_genwalk.inc);
+//   * a stored node holds t_n = P_n p_n, its partial carried through its own branch: the pre-order pass reads it where it would
+//     repeat that product (20 / 60 / 61 states: always; 4 states: between the two streamed walks -- every other reader of stored
+//     partials gets p_n back, ensure_compat_state);
 //   * transition matrices are built on the device from the cached eigen system and reach the 4-state kernels through
 //     wave-uniform (scalar) loads;
 //   * the pre-order pass computes BOTH children's uppers from one read of the parent's upper and fuses the branch-length
